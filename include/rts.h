@@ -1,0 +1,160 @@
+/* =============================================================================
+ * rts.h -- C ABI of the MI355X-native shadow-ray path (librts.so).
+ *
+ * Drop-in boundary for the ONE hot path of kayru/RayTracedShadows:
+ *     BVHBuilder::build  ->  packed vec4 node stream  ->  any-hit shadow kernel
+ * Plain pointers and sizes only; no C++/torch types cross this line.  Every entry
+ * returns an int status (RTS_OK == 0) and never throws.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * the reference checkout).  The reference-side binding a maintainer would add is
+ * shown in INTEGRATION.md.
+ * ========================================================================== */
+#ifndef RTS_H
+#define RTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    RTS_OK              = 0,
+    RTS_ERR_INVALID_ARG = 1, /* NULL pointer, prim_count == 0, bad row range ...           */
+    RTS_ERR_CAPACITY    = 2, /* output buffer too small                                    */
+    RTS_ERR_NONFINITE   = 3, /* NaN/Inf vertex (reference: unbounded recursion, SURVEY E-4) */
+    RTS_ERR_NO_BVH      = 4, /* trace called before rts_ctx_set_bvh                         */
+    RTS_ERR_BAD_BVH     = 5, /* packed buffer fails structural validation                   */
+    RTS_ERR_HIP         = 100 /* 100 + hipError_t                                           */
+};
+const char* rts_status_string(int status);
+
+/* ---- data contract -------------------------------------------------------- */
+
+/* Source/BVHBuilder.h:22-25 `struct BVHPackedNode {u32 a,b,c,d;}` == GLSL `vec4 bvhNodes[]`
+ * (Source/Shaders/RayTracedShadows.comp:23-26).  Layout of the whole buffer: SURVEY.md Appendix A. */
+typedef struct rts_vec4u { uint32_t a, b, c, d; } rts_vec4u;
+
+/* Source/BVHBuilder.h:8-20 `struct BVHNode` (unpacked, DFS order; prim==0xFFFFFFFF <=> inner). */
+typedef struct rts_bvh_node {
+    float bboxMin[3]; uint32_t prim;
+    float bboxMax[3]; uint32_t next;
+} rts_bvh_node;
+
+/* Source/RayTracedShadows.h:56-62 `struct RayTracingConstants` == UBO `Constants`
+ * (RayTracedShadows.comp:3-9).  Only cameraPosition.xyz and lightDirection.xyz are read. */
+typedef struct rts_constants {
+    float cameraPosition[4];
+    float cameraDirection[4];
+    float lightDirection[4];
+    float renderTargetSize[4];
+} rts_constants;
+
+/* RayTracedShadows.comp:28-32 `struct Ray { vec4 o; vec4 d; }`: o.w = tmax, d.w unused. */
+typedef struct rts_ray { float o[4]; float d[4]; } rts_ray;
+
+/* Light model.  type RTS_LIGHT_DIRECTIONAL with xyz = constants.lightDirection.xyz is exactly the
+ * reference (RayTracedShadows.comp:134-146).  RTS_LIGHT_POINT and nsamples > 1 are the extensions
+ * BASELINE.json's configs ask for:
+ *   point : o0 = cam + rel; bias as comp:138-140; dn = (L-o0)/|L-o0|; o = o0 + dn*bias;
+ *           d = L - o (un-normalised); tmax = 1
+ *   nsamples in [2,64]: sample j uses L + offsets[j].xyz; the output byte is the number of
+ *   UNoccluded samples (0..nsamples) instead of 0/1. */
+enum { RTS_LIGHT_DIRECTIONAL = 0, RTS_LIGHT_POINT = 1 };
+typedef struct rts_light {
+    uint32_t type;
+    uint32_t nsamples;      /* 0 or 1 = hard shadow */
+    float    xyz[3];
+    float    reserved;
+    float    offsets[64][4];
+} rts_light;
+
+/* ---- producer: replaces BVHBuilder::build (Source/BVHBuilder.h:31, BVHBuilder.cpp:248-368;
+ *      call site Source/RayTracedShadows.cpp:1031-1037) ---------------------- */
+
+/* m_packedNodes.size() for prim_count triangles = 2*(2P-1) + P = 5P-2 (BVHBuilder.cpp:308-367). */
+size_t rts_bvh_packed_count(uint32_t prim_count);
+/* m_nodes.size() = 2P-1. */
+size_t rts_bvh_node_count(uint32_t prim_count);
+
+/* vertices/stride/indices/prim_count: identical meaning to BVHBuilder::build -- `stride_floats`
+ * is in floats (the reference passes sizeof(Vertex)/sizeof(float) == 8).  out_packed receives
+ * m_packedNodes (capacity in vec4 >= rts_bvh_packed_count); out_nodes (nullable) receives m_nodes.
+ * Tail .d words are 0 (reference: uninitialised). */
+int rts_bvh_build(const float* vertices, uint32_t stride_floats, const uint32_t* indices,
+                  uint32_t prim_count, rts_vec4u* out_packed, size_t out_capacity_vec4,
+                  rts_bvh_node* out_nodes);
+
+/* Same with the two knobs the reference hard-codes: sah_prim_limit (1000000 at BVHBuilder.cpp:83;
+ * ranges larger than this use the spatial-median split) and the number of host threads
+ * (0 = all; the tree does not depend on it). */
+int rts_bvh_build_ex(const float* vertices, uint32_t stride_floats, const uint32_t* indices,
+                     uint32_t prim_count, uint32_t sah_prim_limit, int threads,
+                     rts_vec4u* out_packed, size_t out_capacity_vec4, rts_bvh_node* out_nodes);
+
+/* Structural validation of a packed buffer from ANY producer (ours or the reference's):
+ * count == 5P-2, leaf/inner tags, strictly-forward miss links, tail pointers in range. */
+int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_count_out);
+
+/* ---- consumer: replaces the bind-group + dispatch of
+ *      RayTracedShadowsApp::renderShadowMaskCompute (Source/RayTracedShadows.cpp:570-595) and the
+ *      BVH upload (Source/RayTracedShadows.cpp:1039-1044) ---------------------- */
+
+typedef struct rts_ctx rts_ctx;
+
+/* One context per device; not thread-safe; owns the device copy of the BVH. */
+int rts_ctx_create(int device_ordinal, rts_ctx** out);
+int rts_ctx_destroy(rts_ctx* ctx);
+
+/* == Gfx_CreateBuffer(Storage, stride 16, count, m_packedNodes.data()) (cpp:1039-1044).
+ * Validates, copies H2D once and derives the device-private traversal layout. */
+int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
+
+/* Tuning knobs ("kernel" = variant id, "treelet_nodes", "xcd_swizzle", ...).  Unknown key ->
+ * RTS_ERR_INVALID_ARG.  Results never depend on any option. */
+int rts_ctx_set_option(rts_ctx* ctx, const char* key, int value);
+int rts_ctx_get_option(rts_ctx* ctx, const char* key, int* value);
+
+/* == Gfx_Dispatch(divUp(W,8), divUp(H,8), 1) of RayTracedShadows.comp (cpp:576-592) restricted to
+ * rows [row_begin,row_end) (row stripes for multi-GPU).
+ *   constants : the 64-byte UBO; cameraPosition.xyz is read.  light == NULL means the reference's
+ *               directional light taken from constants->lightDirection.xyz.
+ *   positions : binding 2, RGBA32F W x H, row-major, camera-relative world position (Model.frag:35)
+ *   mask      : binding 3, W x H bytes; 1 = lit, 0 = occluded (comp:148; polarity of the
+ *               reference); rows outside the range are not touched.
+ * HOST pointers; copies in, traces, copies out, synchronises. */
+int rts_trace_shadow_mask(rts_ctx* ctx, const rts_constants* constants, const rts_light* light,
+                          const float* positions, uint32_t W, uint32_t H,
+                          uint32_t row_begin, uint32_t row_end, uint8_t* mask);
+
+/* Same with DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int rts_trace_shadow_mask_device(rts_ctx* ctx, const rts_constants* constants, const rts_light* light,
+                                 const float* d_positions, uint32_t W, uint32_t H,
+                                 uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream);
+
+/* Generic rays (the shader's `Ray`): out[i] = 1 if ray i is NOT occluded.  Host / device forms. */
+int rts_trace_rays(rts_ctx* ctx, const rts_ray* rays, size_t n, uint8_t* out);
+int rts_trace_rays_device(rts_ctx* ctx, const rts_ray* d_rays, size_t n, uint8_t* d_out, void* stream);
+
+/* ---- device-memory and timing plumbing (so callers need no HIP headers) ------ */
+int rts_device_count(int* count);
+int rts_device_malloc(rts_ctx* ctx, void** d_ptr, size_t bytes);
+int rts_device_free(rts_ctx* ctx, void* d_ptr);
+int rts_memcpy_h2d(rts_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int rts_memcpy_d2h(rts_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int rts_stream_synchronize(rts_ctx* ctx, void* stream);
+/* hipEvent pair on `stream` == Gfx_BeginTimer/EndTimer(Timestamp_Shadows) (cpp:572,594).
+ * rts_timer_end records the stop event; rts_timer_elapsed_ms synchronises on it. */
+int rts_timer_begin(rts_ctx* ctx, void* stream);
+int rts_timer_end(rts_ctx* ctx, void* stream);
+int rts_timer_elapsed_ms(rts_ctx* ctx, float* ms);
+/* Name of the kernel the last trace launched (for matching rocprofv3 rows), launches so far. */
+const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTS_H */

@@ -1,0 +1,43 @@
+/* =============================================================================
+ * rts_scene.h -- HARNESS entry points of librts.so (not part of the drop-in path).
+ *
+ * The reference feeds its shadow kernel from a Vulkan G-buffer pass and an OBJ file; neither
+ * exists here, so the harness synthesises the same inputs:
+ *   * rtsh_primary_positions : the RGBA32F "camera-relative world position" target that
+ *     Source/Shaders/Model.frag:35,39 writes (closest hit per pixel centre through the same packed
+ *     BVH; background pixels = (0,0,0,0), i.e. the clear value).
+ *   * rtsh_obj_* : OBJ reader with the semantics of External/zeux_objparser/objparser.cpp and the
+ *     flat-vertex expansion of RayTracedShadowsApp::loadModel (Source/RayTracedShadows.cpp:783-824).
+ * ========================================================================== */
+#ifndef RTS_SCENE_H
+#define RTS_SCENE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rts.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Pinhole camera as set up at Source/RayTracedShadows.cpp:238-242 (vertical fov in radians, lookAt
+ * eye -> target, +Y up).  positions: W*H*4 floats.  hit_count (nullable) receives the number of
+ * pixels that hit geometry.  threads: 0 = all host threads. */
+int rtsh_primary_positions(const rts_vec4u* packed, size_t count_vec4, const float eye[3],
+                           const float target[3], float fovy, uint32_t W, uint32_t H,
+                           float* positions, uint64_t* hit_count, int threads);
+
+/* OBJ ingest.  rtsh_obj_load parses `path` and expands it to the reference's flat
+ * Vertex stream: 8 floats per vertex (position.xyz, normal.xyz, texcoord.uv), indices[i] = i.
+ * Call with vertices == NULL to query *vertex_count (3 per triangle) first.  Returns RTS_OK,
+ * RTS_ERR_INVALID_ARG (cannot open / fails objValidate) or RTS_ERR_CAPACITY. */
+int rtsh_obj_load(const char* path, float* vertices, size_t vertex_capacity, uint32_t* vertex_count,
+                  float bbox_min[3], float bbox_max[3]);
+
+/* The parser's number reader (objparser.cpp:62-131), exposed so tests can pin it. */
+float rtsh_obj_parse_float(const char* text, int* consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTS_SCENE_H */

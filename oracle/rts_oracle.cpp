@@ -1,0 +1,473 @@
+// =============================================================================
+// rts_oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is NOT part of the product.  Only tests/, __graft_entry__.smoke()
+// and bench.py's `cpu_baseline` leg may load it; the product library
+// (raytracedshadows_amd/csrc) never links, includes or calls anything here.
+//
+// What it is: a scalar CPU restatement of the reference's hot path
+//   * BVH producer ....... /root/reference/Source/BVHBuilder.cpp:24-368
+//   * any-hit traversal .. /root/reference/Source/Shaders/RayTracedShadows.comp:41-151
+// written so that every floating-point operation is evaluated exactly as the
+// reference source spells it (no FMA contraction, IEEE divide, GLSL
+// compare-select min/max).
+//
+// Why C++ and not plain C: the reference's tree depends on the tie order of
+// libstdc++'s (unstable) std::sort (BVHBuilder.cpp:92,149,162).  Re-using the
+// same std::sort with the same comparator on the same sequence is the only way
+// to restate that faithfully.
+//
+// PARITY PINNING STATUS: the reference ships no tests, golden vectors or
+// fixtures for this path, its compute shader is GLSL (no glslc / Vulkan device
+// here) and BVHBuilder.cpp needs headers of the absent, un-vendored `librush`
+// submodule, so it is unbuildable here without writing stand-ins.  The only
+// recorded output of the real reference builder is the 4-triangle dump in
+// SURVEY.md Appendix A, which this oracle reproduces byte-for-byte
+// (tests/test_oracle_golden.py).  Beyond that vector: "parity unpinned".
+// Assumed librush math semantics: Box3::expandInit =
+// {+FLT_MAX,-FLT_MAX}, Box3::expand = componentwise min/max,
+// Box3::center = (min+max)*0.5f, Box3::dimensions = max-min.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, no -ffast-math).
+// =============================================================================
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+typedef uint32_t u32;
+static const u32 kInvalid = 0xFFFFFFFFu;
+
+static inline u32 f2u(float f) { u32 u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(u32 u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ----------------------------------------------------------------------------
+// Builder restatement
+// ----------------------------------------------------------------------------
+
+// BVHBuilder.cpp:8-22 (TempNode : BVHNode).  primArea is dead in the reference
+// (computed cpp:275, never read) and is omitted.
+struct ONode {
+    float lo[3]; u32 prim;      // BVHNode::bboxMin, prim      (BVHBuilder.h:13-14)
+    float hi[3]; u32 next;      // BVHNode::bboxMax, next      (BVHBuilder.h:16-17)
+    u32 order, parent, left, right;
+    float ctr[3];
+    float saL, saR;
+};
+
+struct OBox { float lo[3], hi[3]; };
+
+static inline void boxInit(OBox& b) {              // librush Box3::expandInit (assumed)
+    for (int k = 0; k < 3; ++k) { b.lo[k] = FLT_MAX; b.hi[k] = -FLT_MAX; }
+}
+static inline void boxExpand(OBox& b, const float* p) { // librush Box3::expand (assumed)
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = (p[k] < b.lo[k]) ? p[k] : b.lo[k];
+        b.hi[k] = (b.hi[k] < p[k]) ? p[k] : b.hi[k];
+    }
+}
+
+// BVHBuilder.cpp:24-28
+static inline float surfaceArea(const float* lo, const float* hi) {
+    float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return (ex * ey + ey * ez + ez * ex) * 2.0f;
+}
+
+// BVHBuilder.cpp:53-76.  _mm_min_ps(a,b) = a<b ? a : b ; _mm_max_ps(a,b) = a>b ? a : b.
+static OBox rangeBounds(const std::vector<ONode>& n, u32 begin, u32 end) {
+    OBox r;
+    if (begin == end) {
+        for (int k = 0; k < 3; ++k) { r.lo[k] = 0.0f; r.hi[k] = 0.0f; }
+        return r;
+    }
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (u32 i = begin; i < end; ++i)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = (mn[k] < n[i].lo[k]) ? mn[k] : n[i].lo[k];
+            mx[k] = (mx[k] > n[i].hi[k]) ? mx[k] : n[i].hi[k];
+        }
+    for (int k = 0; k < 3; ++k) { r.lo[k] = mn[k]; r.hi[k] = mx[k]; }
+    return r;
+}
+
+// BVHBuilder.cpp:78-179
+static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nodeBounds, u32 sahLimit) {
+    const u32 count = end - begin;
+    u32 bestSplit = begin;                                    // cpp:81 (carried across axes)
+    if (count <= sahLimit) {                                  // cpp:83 (1000000 in the reference)
+        u32 bestAxis = 0, globalBestSplit = begin;
+        float globalBestCost = FLT_MAX;
+        for (u32 axis = 0; axis < 3; ++axis) {
+            std::sort(n.begin() + begin, n.begin() + end,     // cpp:92-96
+                      [axis](const ONode& a, const ONode& b) { return a.ctr[axis] < b.ctr[axis]; });
+            OBox bl, br; boxInit(bl); boxInit(br);
+            for (u32 il = 0; il < count; ++il) {              // cpp:104-119
+                u32 ir = count - il - 1;
+                boxExpand(bl, n[begin + il].lo); boxExpand(bl, n[begin + il].hi);
+                boxExpand(br, n[begin + ir].lo); boxExpand(br, n[begin + ir].hi);
+                n[begin + il].saL = surfaceArea(bl.lo, bl.hi);
+                n[begin + ir].saR = surfaceArea(br.lo, br.hi);
+            }
+            float bestCost = FLT_MAX;
+            for (u32 mid = begin + 1; mid < end; ++mid) {     // cpp:121-139
+                float costL = n[mid - 1].saL * (float)(mid - begin);
+                float costR = n[mid].saR * (float)(end - mid);
+                float cost = costL + costR;
+                if (cost < bestCost) { bestSplit = mid; bestCost = cost; }
+            }
+            if (bestCost < globalBestCost) {                  // cpp:141-146
+                globalBestSplit = bestSplit; globalBestCost = bestCost; bestAxis = axis;
+            }
+        }
+        std::sort(n.begin() + begin, n.begin() + end,         // cpp:149-153
+                  [bestAxis](const ONode& a, const ONode& b) { return a.ctr[bestAxis] < b.ctr[bestAxis]; });
+        return globalBestSplit;
+    }
+    // cpp:157-178: spatial median on the widest axis (first maximum wins, std::max_element)
+    float ext[3] = { nodeBounds.hi[0] - nodeBounds.lo[0], nodeBounds.hi[1] - nodeBounds.lo[1],
+                     nodeBounds.hi[2] - nodeBounds.lo[2] };
+    int major = 0;
+    for (int k = 1; k < 3; ++k) if (ext[major] < ext[k]) major = k;
+    std::sort(n.begin() + begin, n.begin() + end,
+              [major](const ONode& a, const ONode& b) { return a.ctr[major] < b.ctr[major]; });
+    float splitPos = (nodeBounds.lo[major] + nodeBounds.hi[major]) * 0.5f;
+    for (u32 mid = begin + 1; mid < end; ++mid)
+        if (n[mid].ctr[major] >= splitPos) return mid;
+    return end - 1;
+}
+
+// BVHBuilder.cpp:181-220
+static u32 buildRange(std::vector<ONode>& n, u32 begin, u32 end, u32 sahLimit) {
+    if (end - begin == 1) return begin;
+    OBox bounds = rangeBounds(n, begin, end);
+    u32 mid = splitRange(n, begin, end, bounds, sahLimit);
+    u32 id = (u32)n.size();
+    n.push_back(ONode());
+    ONode node; memset(&node, 0, sizeof(node));
+    node.order = kInvalid; node.parent = kInvalid; node.next = kInvalid;
+    node.left = buildRange(n, begin, mid, sahLimit);
+    node.right = buildRange(n, mid, end, sahLimit);
+    float saLeft = surfaceArea(n[node.left].lo, n[node.left].hi);
+    float saRight = surfaceArea(n[node.right].lo, n[node.right].hi);
+    if (saRight > saLeft) std::swap(node.left, node.right);   // cpp:205-208
+    for (int k = 0; k < 3; ++k) {
+        node.lo[k] = bounds.lo[k]; node.hi[k] = bounds.hi[k];
+        node.ctr[k] = (bounds.lo[k] + bounds.hi[k]) * 0.5f;   // Box3::center (assumed)
+    }
+    node.prim = kInvalid;
+    n[node.left].parent = id; n[node.right].parent = id;
+    n[id] = node;
+    return id;
+}
+
+// BVHBuilder.cpp:222-238
+static void dfsOrder(std::vector<ONode>& n, u32 id, u32 nextId, u32& order) {
+    n[id].order = order++;
+    n[id].next = nextId;
+    u32 l = n[id].left, r = n[id].right;
+    if (l != kInvalid) dfsOrder(n, l, r, order);
+    if (r != kInvalid) dfsOrder(n, r, nextId, order);
+}
+
+// ----------------------------------------------------------------------------
+// Traversal restatement (RayTracedShadows.comp)
+// ----------------------------------------------------------------------------
+
+// GLSL 4.50 spec 8.3: min(x,y) = y<x ? y : x ; max(x,y) = x<y ? y : x
+static inline float gmin(float x, float y) { return (y < x) ? y : x; }
+static inline float gmax(float x, float y) { return (x < y) ? y : x; }
+
+struct V3 { float x, y, z; };
+static inline V3 crossv(V3 a, V3 b) {    // GLSL cross()
+    V3 r; r.x = a.y * b.z - b.y * a.z; r.y = a.z * b.x - b.z * a.x; r.z = a.x * b.y - b.x * a.y; return r;
+}
+static inline float dotv(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 subv(V3 a, V3 b) { V3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+
+// comp:41-59
+static inline bool rayTri(V3 o, float tmax, V3 d, V3 v0, V3 e0, V3 e1) {
+    V3 s1 = crossv(d, e1);
+    float invd = 1.0f / dotv(s1, e0);
+    V3 dd = subv(o, v0);
+    float b1 = dotv(dd, s1) * invd;
+    V3 s2 = crossv(dd, e0);
+    float b2 = dotv(d, s2) * invd;
+    float t = dotv(e1, s2) * invd;
+    if (b1 < 0.0f || b1 > 1.0f || b2 < 0.0f || b1 + b2 > 1.0f || t < 0.0f || t > tmax) return false;
+    return true;
+}
+
+// comp:61-73
+static inline bool rayBox(V3 o, V3 invdir, V3 pmin, V3 pmax) {
+    float fx = (pmax.x - o.x) * invdir.x, fy = (pmax.y - o.y) * invdir.y, fz = (pmax.z - o.z) * invdir.z;
+    float nx = (pmin.x - o.x) * invdir.x, ny = (pmin.y - o.y) * invdir.y, nz = (pmin.z - o.z) * invdir.z;
+    float tmaxx = gmax(fx, nx), tmaxy = gmax(fy, ny), tmaxz = gmax(fz, nz);
+    float tminx = gmin(fx, nx), tminy = gmin(fy, ny), tminz = gmin(fz, nz);
+    float t1 = gmin(tmaxx, gmin(tmaxy, tmaxz));
+    float t0 = gmax(gmax(tminx, gmax(tminy, tminz)), 0.0f);
+    return t1 >= t0;
+}
+
+// comp:75-111.  `bvh` = packed vec4 stream (4 u32 per vec4).  Counts nodes visited (V) and
+// triangle tests (L) for the algorithmic-bytes figure.
+static inline bool anyHit(const u32* bvh, V3 o, float tmax, V3 d, u32* V, u32* L) {
+    V3 invdir = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    u32 node = 0, v = 0, l = 0;
+    bool hit = false;
+    while (node != kInvalid) {
+        const u32* a = bvh + (size_t)node * 8;
+        const u32* b = a + 4;
+        ++v;
+        u32 prim = a[3];
+        if (prim != kInvalid) {
+            const u32* t = bvh + (size_t)prim * 4;
+            V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) };
+            V3 e1 = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+            V3 v0 = { u2f(t[0]), u2f(t[1]), u2f(t[2]) };
+            ++l;
+            if (rayTri(o, tmax, d, v0, e0, e1)) { hit = true; break; }
+        } else {
+            V3 pmin = { u2f(a[0]), u2f(a[1]), u2f(a[2]) };
+            V3 pmax = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+            if (rayBox(o, invdir, pmin, pmax)) { ++node; continue; }
+        }
+        node = b[3];
+    }
+    if (V) *V = v;
+    if (L) *L = l;
+    return hit;
+}
+
+// comp:113-120
+static inline float epsilonFor(float f, u32 diff) {
+    u32 u = f2u(f);
+    u32 e = (u >> 23) & 0xFFu;
+    e -= (diff < e) ? diff : e;
+    u = (u & ~(0xFFu << 23)) | (e << 23);
+    return u2f(u);
+}
+static inline float max3abs(V3 v) { return gmax(gmax(fabsf(v.x), fabsf(v.y)), fabsf(v.z)); }
+
+// Light description shared with the product API (include/rts.h: rts_light).
+//   type 0: directional, xyz = direction  -> exactly comp:128-151
+//   type 1: point light at xyz (extension, BASELINE.json configs 2-5):
+//           o0 = cam+rel; bias as comp:138-140; dn = (L-o0)/|L-o0|; o = o0 + dn*bias; d = L-o; tmax = 1
+//   nsamples>1: sample j uses light xyz + offsets[j]; output = number of UNoccluded samples.
+struct OLight { u32 type; u32 nsamples; float xyz[3]; float pad; float offsets[64][4]; };
+
+static inline void genRay(const float* cam, V3 rel, const OLight& lt, u32 j, V3* o, float* tmax, V3* d) {
+    V3 origin = { cam[0] + rel.x, cam[1] + rel.y, cam[2] + rel.z };                  // comp:136
+    float bias = gmax(epsilonFor(max3abs(origin), 13), epsilonFor(max3abs(rel), 13)); // comp:138-140
+    V3 L = { lt.xyz[0], lt.xyz[1], lt.xyz[2] };
+    if (lt.nsamples > 1) { L.x = L.x + lt.offsets[j][0]; L.y = L.y + lt.offsets[j][1]; L.z = L.z + lt.offsets[j][2]; }
+    if (lt.type == 0) {
+        origin.x = origin.x + L.x * bias; origin.y = origin.y + L.y * bias; origin.z = origin.z + L.z * bias; // comp:143
+        *o = origin; *tmax = 1e9f; *d = L;                                            // comp:145-146
+    } else {
+        V3 d0 = subv(L, origin);
+        float inv = 1.0f / sqrtf(dotv(d0, d0));
+        origin.x = origin.x + (d0.x * inv) * bias; origin.y = origin.y + (d0.y * inv) * bias;
+        origin.z = origin.z + (d0.z * inv) * bias;
+        *o = origin; *tmax = 1.0f; *d = subv(L, origin);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// Number of vec4 in the packed buffer: 2N + P with N = 2P-1 (BVHBuilder.cpp:308-367).
+uint64_t orc_packed_count(uint32_t P) { return P ? 5ull * P - 2 : 0; }
+
+// Restates BVHBuilder::build (cpp:248-368).  out_packed: 4*(5P-2) u32.  out_nodes (optional):
+// 8*N u32 = m_nodes (BVHNode, 32 B each).  Tail .w words are written as 0 (reference: stack
+// garbage).  sah_limit = 1000000 reproduces cpp:83; tests may lower it to reach
+// the median-split branch on small inputs.  Returns 0, or -1 on P==0.
+int orc_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                  uint32_t sah_limit, uint32_t* out_packed, uint32_t* out_nodes) {
+    if (P == 0) return -1;
+    std::vector<ONode> n;
+    n.reserve((size_t)P * 2 - 1);
+    for (u32 p = 0; p < P; ++p) {                              // cpp:261-284
+        ONode node; memset(&node, 0, sizeof(node));
+        OBox box; boxInit(box);
+        for (int c = 0; c < 3; ++c) boxExpand(box, vertices + (size_t)stride * indices[p * 3 + c]);
+        for (int k = 0; k < 3; ++k) {
+            node.lo[k] = box.lo[k]; node.hi[k] = box.hi[k];
+            node.ctr[k] = (box.lo[k] + box.hi[k]) * 0.5f;
+        }
+        node.prim = p; node.next = kInvalid; node.order = kInvalid; node.parent = kInvalid;
+        node.left = kInvalid; node.right = kInvalid;
+        n.push_back(node);
+    }
+    u32 root = buildRange(n, 0, P, sah_limit);                 // cpp:286
+    u32 order = 0;
+    dfsOrder(n, root, kInvalid, order);                        // cpp:288
+    const u32 N = (u32)n.size();
+    std::vector<ONode> dfs(N);                                 // m_nodes, cpp:290-306
+    for (u32 i = 0; i < N; ++i) {
+        ONode& dst = dfs[n[i].order];
+        dst = n[i];
+        dst.next = (n[i].next == kInvalid) ? kInvalid : n[n[i].next].order;
+    }
+    u32* out = out_packed;
+    for (u32 i = 0; i < N; ++i) {                              // cpp:310-359
+        const ONode& nd = dfs[i];
+        if (out_nodes) {
+            u32* o = out_nodes + (size_t)i * 8;
+            o[0] = f2u(nd.lo[0]); o[1] = f2u(nd.lo[1]); o[2] = f2u(nd.lo[2]); o[3] = nd.prim;
+            o[4] = f2u(nd.hi[0]); o[5] = f2u(nd.hi[1]); o[6] = f2u(nd.hi[2]); o[7] = nd.next;
+        }
+        if (nd.prim != kInvalid) {
+            const float* v0 = vertices + (size_t)stride * indices[nd.prim * 3 + 0];
+            const float* v1 = vertices + (size_t)stride * indices[nd.prim * 3 + 1];
+            const float* v2 = vertices + (size_t)stride * indices[nd.prim * 3 + 2];
+            out[0] = f2u(v1[0] - v0[0]); out[1] = f2u(v1[1] - v0[1]); out[2] = f2u(v1[2] - v0[2]);
+            out[3] = nd.prim + N * 2;                          // cpp:331
+            out[4] = f2u(v2[0] - v0[0]); out[5] = f2u(v2[1] - v0[1]); out[6] = f2u(v2[2] - v0[2]);
+            out[7] = nd.next;
+        } else {
+            out[0] = f2u(nd.lo[0]); out[1] = f2u(nd.lo[1]); out[2] = f2u(nd.lo[2]); out[3] = kInvalid;
+            out[4] = f2u(nd.hi[0]); out[5] = f2u(nd.hi[1]); out[6] = f2u(nd.hi[2]); out[7] = nd.next;
+        }
+        out += 8;
+    }
+    for (u32 p = 0; p < P; ++p) {                              // cpp:361-367
+        const float* v0 = vertices + (size_t)stride * indices[p * 3 + 0];
+        out[0] = f2u(v0[0]); out[1] = f2u(v0[1]); out[2] = f2u(v0[2]); out[3] = 0;
+        out += 4;
+    }
+    return 0;
+}
+
+// One generic ray {o.xyz, tmax} {d.xyz, 0} (the shader's `Ray`, comp:28-32).  Returns 1 on hit.
+int orc_any_hit(const uint32_t* packed, const float* o4, const float* d4, uint32_t* V, uint32_t* L) {
+    V3 o = { o4[0], o4[1], o4[2] }, d = { d4[0], d4[1], d4[2] };
+    return anyHit(packed, o, o4[3], d, V, L) ? 1 : 0;
+}
+
+// n generic rays (8 floats each).  out[i] = 1 if NOT occluded (reference polarity, comp:148).
+// sums[0] += nodes visited, sums[1] += triangle tests (may be NULL).
+void orc_trace_rays(const uint32_t* packed, const float* rays, uint64_t n, uint8_t* out,
+                    uint64_t* sums, int threads) {
+    uint64_t sv = 0, sl = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : sv, sl)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const float* r = rays + i * 8;
+        V3 o = { r[0], r[1], r[2] }, d = { r[4], r[5], r[6] };
+        u32 v, l;
+        out[i] = anyHit(packed, o, r[3], d, &v, &l) ? 0 : 1;
+        sv += v; sl += l;
+    }
+    if (sums) { sums[0] += sv; sums[1] += sl; }
+}
+
+// The dispatch of RayTracedShadows.cpp:570-595 + comp:128-151 over rows [row_begin,row_end) of a
+// W x H frame.  constants: 16 floats = RayTracingConstants (RayTracedShadows.h:56-62); only
+// cameraPosition.xyz is read here, the light comes from `light` (type 0 with xyz = constants'
+// lightDirection.xyz is exactly the reference).  positions: W*H*4 floats (RGBA32F, camera-relative).
+// mask: W*H bytes, rows outside the range untouched; value = number of unoccluded samples
+// (0/1 for one sample).  per_ray_v / per_ray_l (optional, W*H u32; summed over samples).
+void orc_shadow_mask(const uint32_t* packed, const float* constants, const void* light_v,
+                     const float* positions, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                     uint8_t* mask, uint64_t* sums, uint32_t* per_ray_v, uint32_t* per_ray_l, int threads) {
+    const OLight& lt = *(const OLight*)light_v;
+    const u32 ns = lt.nsamples ? lt.nsamples : 1;
+    uint64_t sv = 0, sl = 0;
+    (void)H;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : sv, sl)
+#endif
+    for (int64_t y = row_begin; y < (int64_t)row_end; ++y) {
+        for (u32 x = 0; x < W; ++x) {
+            size_t pix = (size_t)y * W + x;
+            V3 rel = { positions[pix * 4 + 0], positions[pix * 4 + 1], positions[pix * 4 + 2] }; // comp:135
+            u32 lit = 0, pv = 0, pl = 0;
+            for (u32 j = 0; j < ns; ++j) {
+                V3 o, d; float tmax;
+                genRay(constants, rel, lt, j, &o, &tmax, &d);
+                u32 v, l;
+                lit += anyHit(packed, o, tmax, d, &v, &l) ? 0 : 1;                         // comp:148
+                pv += v; pl += l;
+            }
+            mask[pix] = (uint8_t)lit;
+            sv += pv; sl += pl;
+            if (per_ray_v) per_ray_v[pix] = pv;
+            if (per_ray_l) per_ray_l[pix] = pl;
+        }
+    }
+    if (sums) { sums[0] += sv; sums[1] += sl; }
+}
+
+// Writes the rays the mask dispatch would generate (8 floats per ray, sample-major within a pixel).
+void orc_gen_rays(const float* constants, const void* light_v, const float* positions, uint64_t npix, float* rays) {
+    const OLight& lt = *(const OLight*)light_v;
+    const u32 ns = lt.nsamples ? lt.nsamples : 1;
+    for (uint64_t p = 0; p < npix; ++p) {
+        V3 rel = { positions[p * 4 + 0], positions[p * 4 + 1], positions[p * 4 + 2] };
+        for (u32 j = 0; j < ns; ++j) {
+            V3 o, d; float tmax;
+            genRay(constants, rel, lt, j, &o, &tmax, &d);
+            float* r = rays + (p * ns + j) * 8;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = tmax; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = 0.0f;
+        }
+    }
+}
+
+// Independent check of the oracle itself: brute-force any-hit over ALL leaves of the packed
+// buffer with the same triangle test and no box culling.  out[i] = 1 if not occluded.
+void orc_brute_force_rays(const uint32_t* packed, uint32_t P, const float* rays, uint64_t n, uint8_t* out) {
+    const u32 N = 2 * P - 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const float* r = rays + i * 8;
+        V3 o = { r[0], r[1], r[2] }, d = { r[4], r[5], r[6] };
+        bool hit = false;
+        for (u32 k = 0; k < N && !hit; ++k) {
+            const u32* a = packed + (size_t)k * 8;
+            if (a[3] == kInvalid) continue;
+            const u32* t = packed + (size_t)a[3] * 4;
+            V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(a[4]), u2f(a[5]), u2f(a[6]) };
+            V3 v0 = { u2f(t[0]), u2f(t[1]), u2f(t[2]) };
+            hit = rayTri(o, r[3], d, v0, e0, e1);
+        }
+        out[i] = hit ? 0 : 1;
+    }
+}
+
+// Single-call helpers so tests can pin the scalar pieces (KATs).
+int orc_ray_box(const float* o3, const float* invdir3, const float* pmin3, const float* pmax3) {
+    V3 o = { o3[0], o3[1], o3[2] }, i = { invdir3[0], invdir3[1], invdir3[2] };
+    V3 a = { pmin3[0], pmin3[1], pmin3[2] }, b = { pmax3[0], pmax3[1], pmax3[2] };
+    return rayBox(o, i, a, b) ? 1 : 0;
+}
+int orc_ray_tri(const float* o4, const float* d3, const float* v03, const float* e03, const float* e13) {
+    V3 o = { o4[0], o4[1], o4[2] }, d = { d3[0], d3[1], d3[2] };
+    V3 v0 = { v03[0], v03[1], v03[2] }, e0 = { e03[0], e03[1], e03[2] }, e1 = { e13[0], e13[1], e13[2] };
+    return rayTri(o, o4[3], d, v0, e0, e1) ? 1 : 0;
+}
+float orc_epsilon_for(float f, uint32_t diff) { return epsilonFor(f, diff); }
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"

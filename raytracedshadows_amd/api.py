@@ -1,0 +1,329 @@
+"""ctypes view of ``librts.so`` (C ABI: ``include/rts.h`` / ``include/rts_scene.h``).
+
+Mirrors the reference's interface for the shadow path:
+
+* :class:`BVHBuilder` -- ``BVHBuilder::build(vertices, stride, indices, primCount)`` with the
+  public members ``m_nodes`` / ``m_packedNodes`` (reference ``Source/BVHBuilder.h:27-32``).
+* :class:`RayTracingConstants` -- the 64-byte UBO (``Source/RayTracedShadows.h:56-62``).
+* :class:`ShadowContext` -- owns the device BVH buffer and issues the dispatch that
+  ``RayTracedShadowsApp::renderShadowMaskCompute`` issues (``Source/RayTracedShadows.cpp:570-595``).
+
+No CPU fallback exists here by design: a missing library raises at import, a missing GPU raises
+at context creation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "librts.so")
+
+
+class RtsError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.rts_status_string(status).decode() if _lib is not None else "?"
+        super().__init__(f"{where}: rts status {status} ({msg})")
+
+
+def _load():
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the shadow path.")
+    return C.CDLL(path)
+
+
+_lib = None
+_lib = _load()
+
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class RayTracingConstants(C.Structure):
+    """``struct RayTracingConstants`` (RayTracedShadows.h:56-62) == UBO ``Constants`` (comp:3-9)."""
+    _fields_ = [("cameraPosition", C.c_float * 4), ("cameraDirection", C.c_float * 4),
+                ("lightDirection", C.c_float * 4), ("renderTargetSize", C.c_float * 4)]
+
+    @classmethod
+    def make(cls, camera_position, light_direction, width, height, camera_direction=(0, 0, -1)):
+        k = cls()
+        for i in range(3):
+            k.cameraPosition[i] = np.float32(camera_position[i])
+            k.cameraDirection[i] = np.float32(camera_direction[i])
+            k.lightDirection[i] = np.float32(light_direction[i])
+        k.renderTargetSize[0] = width
+        k.renderTargetSize[1] = height
+        k.renderTargetSize[2] = 1.0 / width
+        k.renderTargetSize[3] = 1.0 / height
+        return k
+
+    def as_array(self):
+        return np.frombuffer(bytes(self), dtype=np.float32).copy()
+
+
+class Light(C.Structure):
+    """``rts_light``: directional (the reference) / point light, 1..64 samples."""
+    _fields_ = [("type", C.c_uint32), ("nsamples", C.c_uint32), ("xyz", C.c_float * 3),
+                ("reserved", C.c_float), ("offsets", (C.c_float * 4) * 64)]
+    DIRECTIONAL = 0
+    POINT = 1
+
+    @classmethod
+    def make(cls, kind, xyz, offsets=None):
+        lt = cls()
+        lt.type = kind
+        for i in range(3):
+            lt.xyz[i] = np.float32(xyz[i])
+        lt.nsamples = 1
+        if offsets is not None:
+            offsets = np.asarray(offsets, dtype=np.float32)
+            lt.nsamples = offsets.shape[0]
+            for j in range(offsets.shape[0]):
+                for i in range(3):
+                    lt.offsets[j][i] = offsets[j, i]
+        return lt
+
+
+#: numpy view of ``struct BVHNode`` (BVHBuilder.h:8-20)
+BVHNode_dtype = np.dtype([("bboxMin", np.float32, 3), ("prim", np.uint32),
+                          ("bboxMax", np.float32, 3), ("next", np.uint32)])
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(_lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("rts_status_string", C.c_char_p, C.c_int)
+_sig("rts_bvh_packed_count", C.c_size_t, C.c_uint32)
+_sig("rts_bvh_node_count", C.c_size_t, C.c_uint32)
+_sig("rts_bvh_build", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("rts_bvh_build_ex", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+     C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("rts_bvh_validate", C.c_int, C.c_void_p, C.c_size_t, _u32p)
+_sig("rts_device_count", C.c_int, C.POINTER(C.c_int))
+_sig("rts_ctx_create", C.c_int, C.c_int, C.POINTER(C.c_void_p))
+_sig("rts_ctx_destroy", C.c_int, C.c_void_p)
+_sig("rts_ctx_set_bvh", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_ctx_set_option", C.c_int, C.c_void_p, C.c_char_p, C.c_int)
+_sig("rts_ctx_get_option", C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int))
+_sig("rts_trace_shadow_mask", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p,
+     C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
+_sig("rts_trace_shadow_mask_device", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light),
+     C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
+_sig("rts_trace_rays", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("rts_trace_rays_device", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+_sig("rts_device_malloc", C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t)
+_sig("rts_device_free", C.c_int, C.c_void_p, C.c_void_p)
+_sig("rts_memcpy_h2d", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_memcpy_d2h", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_stream_synchronize", C.c_int, C.c_void_p, C.c_void_p)
+_sig("rts_timer_begin", C.c_int, C.c_void_p, C.c_void_p)
+_sig("rts_timer_end", C.c_int, C.c_void_p, C.c_void_p)
+_sig("rts_timer_elapsed_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
+_sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
+_sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
+     C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
+_sig("rtsh_obj_load", C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, _u32p, _f32p, _f32p)
+_sig("rtsh_obj_parse_float", C.c_float, C.c_char_p, C.POINTER(C.c_int))
+
+
+def _check(status, where):
+    if status != 0:
+        raise RtsError(status, where)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def packed_count(prim_count):
+    """``m_packedNodes.size()`` for ``prim_count`` triangles (= 5P-2)."""
+    return int(_lib.rts_bvh_packed_count(prim_count))
+
+
+def bvh_validate(packed):
+    packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1, 4)
+    p = C.c_uint32(0)
+    _check(_lib.rts_bvh_validate(_ptr(packed), packed.shape[0], C.byref(p)), "rts_bvh_validate")
+    return int(p.value)
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib.rts_device_count(C.byref(n))
+    return int(n.value)
+
+
+class BVHBuilder:
+    """Same surface as the reference's ``struct BVHBuilder`` (Source/BVHBuilder.h:27-32).
+
+    ``m_nodes``: structured array of ``BVHNode`` (2P-1), ``m_packedNodes``: ``uint32[5P-2, 4]``
+    (one row per ``BVHPackedNode`` / GLSL ``vec4``).
+    """
+
+    def __init__(self, sah_prim_limit=1000000, threads=0):
+        self.m_nodes = np.zeros(0, dtype=BVHNode_dtype)
+        self.m_packedNodes = np.zeros((0, 4), dtype=np.uint32)
+        self.sah_prim_limit = sah_prim_limit
+        self.threads = threads
+
+    def build(self, vertices, stride, indices, primCount):
+        """``stride`` is in floats, exactly like the reference (it passes 8)."""
+        vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        if primCount > 0:
+            if indices.size < 3 * primCount:
+                raise RtsError(1, "BVHBuilder.build: indices shorter than 3*primCount")
+            if vertices.size < (int(indices[:3 * primCount].max()) * stride + 3):
+                raise RtsError(1, "BVHBuilder.build: index out of range of the vertex array")
+        n = packed_count(primCount)
+        packed = np.zeros((max(n, 1), 4), dtype=np.uint32)
+        nodes = np.zeros(max(2 * primCount - 1, 1), dtype=BVHNode_dtype)
+        st = _lib.rts_bvh_build_ex(_ptr(vertices), stride, _ptr(indices), primCount, self.sah_prim_limit,
+                                   self.threads, _ptr(packed), packed.shape[0], _ptr(nodes))
+        _check(st, "rts_bvh_build")
+        self.m_packedNodes = packed[:n]
+        self.m_nodes = nodes[:2 * primCount - 1]
+        return self
+
+
+class ShadowContext:
+    """Device-side half of the path: BVH storage buffer + the shadow dispatch."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(_lib.rts_ctx_create(device, C.byref(h)), "rts_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.rts_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_bvh(self, packed):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1, 4)
+        _check(_lib.rts_ctx_set_bvh(self._h, _ptr(packed), packed.shape[0]), "rts_ctx_set_bvh")
+
+    def set_option(self, key, value):
+        _check(_lib.rts_ctx_set_option(self._h, key.encode(), int(value)), f"rts_ctx_set_option({key})")
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        _check(_lib.rts_ctx_get_option(self._h, key.encode(), C.byref(v)), f"rts_ctx_get_option({key})")
+        return int(v.value)
+
+    def trace_shadow_mask(self, constants, positions, width, height, light=None, row_begin=0, row_end=None,
+                          out=None):
+        """Host-pointer dispatch; returns the ``uint8[H, W]`` mask (1 = lit)."""
+        positions = np.ascontiguousarray(positions, dtype=np.float32)
+        if positions.size != width * height * 4:
+            raise RtsError(1, "trace_shadow_mask: positions must be W*H*4 floats")
+        row_end = height if row_end is None else row_end
+        mask = out if out is not None else np.zeros((height, width), dtype=np.uint8)
+        lp = C.byref(light) if light is not None else None
+        _check(_lib.rts_trace_shadow_mask(self._h, C.byref(constants), lp, _ptr(positions), width, height,
+                                          row_begin, row_end, _ptr(mask)), "rts_trace_shadow_mask")
+        return mask
+
+    def trace_shadow_mask_device(self, constants, d_positions, width, height, d_mask, light=None, row_begin=0,
+                                 row_end=None, stream=None):
+        row_end = height if row_end is None else row_end
+        lp = C.byref(light) if light is not None else None
+        _check(_lib.rts_trace_shadow_mask_device(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width,
+                                                 height, row_begin, row_end, C.c_void_p(d_mask),
+                                                 C.c_void_p(stream or 0)), "rts_trace_shadow_mask_device")
+
+    def trace_rays(self, rays):
+        """``rays``: float32[n, 8] = {o.xyz, tmax, d.xyz, 0}; returns uint8[n] (1 = not occluded)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], dtype=np.uint8)
+        _check(_lib.rts_trace_rays(self._h, _ptr(rays), rays.shape[0], _ptr(out)), "rts_trace_rays")
+        return out
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        _check(_lib.rts_device_malloc(self._h, C.byref(p), nbytes), "rts_device_malloc")
+        return p.value
+
+    def free(self, ptr):
+        _check(_lib.rts_device_free(self._h, C.c_void_p(ptr)), "rts_device_free")
+
+    def h2d(self, dptr, array):
+        array = np.ascontiguousarray(array)
+        _check(_lib.rts_memcpy_h2d(self._h, C.c_void_p(dptr), _ptr(array), array.nbytes), "rts_memcpy_h2d")
+
+    def d2h(self, array, dptr):
+        _check(_lib.rts_memcpy_d2h(self._h, _ptr(array), C.c_void_p(dptr), array.nbytes), "rts_memcpy_d2h")
+
+    def synchronize(self, stream=None):
+        _check(_lib.rts_stream_synchronize(self._h, C.c_void_p(stream or 0)), "rts_stream_synchronize")
+
+    def timer_begin(self, stream=None):
+        _check(_lib.rts_timer_begin(self._h, C.c_void_p(stream or 0)), "rts_timer_begin")
+
+    def timer_end(self, stream=None):
+        _check(_lib.rts_timer_end(self._h, C.c_void_p(stream or 0)), "rts_timer_end")
+
+    def timer_elapsed_ms(self):
+        ms = C.c_float(0)
+        _check(_lib.rts_timer_elapsed_ms(self._h, C.byref(ms)), "rts_timer_elapsed_ms")
+        return float(ms.value)
+
+    def last_kernel_name(self):
+        return _lib.rts_ctx_last_kernel_name(self._h).decode()
+
+
+# -- harness entry points -----------------------------------------------------------------------
+def primary_positions(packed, eye, target, fovy, width, height, threads=0):
+    """G-buffer position target (camera-relative closest hit per pixel); see include/rts_scene.h."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1, 4)
+    pos = np.zeros((height, width, 4), dtype=np.float32)
+    e = (C.c_float * 3)(*[float(x) for x in eye])
+    t = (C.c_float * 3)(*[float(x) for x in target])
+    hits = C.c_uint64(0)
+    _check(_lib.rtsh_primary_positions(_ptr(packed), packed.shape[0], e, t, fovy, width, height, _ptr(pos),
+                                       C.byref(hits), threads), "rtsh_primary_positions")
+    return pos, int(hits.value)
+
+
+def obj_load(path):
+    """OBJ -> flat ``float32[3T, 8]`` Vertex stream + ``indices[i] = i`` (loadModel semantics)."""
+    n = C.c_uint32(0)
+    _check(_lib.rtsh_obj_load(path.encode(), None, 0, C.byref(n), None, None), "rtsh_obj_load")
+    verts = np.zeros((max(n.value, 1), 8), dtype=np.float32)
+    lo = (C.c_float * 3)()
+    hi = (C.c_float * 3)()
+    _check(_lib.rtsh_obj_load(path.encode(), _ptr(verts), verts.shape[0], C.byref(n), lo, hi), "rtsh_obj_load")
+    verts = verts[:n.value]
+    return verts, np.arange(n.value, dtype=np.uint32), np.array(lo[:], np.float32), np.array(hi[:], np.float32)
+
+
+def obj_parse_float(text):
+    used = C.c_int(0)
+    v = _lib.rtsh_obj_parse_float(text.encode(), C.byref(used))
+    return np.float32(v), int(used.value)

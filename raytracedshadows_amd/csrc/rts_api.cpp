@@ -1,0 +1,315 @@
+// C ABI of librts.so (declared in include/rts.h): thin, exception-free glue between plain
+// pointers and (a) the host BVH producer, (b) the HIP traversal kernels.
+#include "../../include/rts.h"
+#include "bvh_builder.h"
+#include "rts_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using rts::TraceParams;
+
+struct rts_ctx {
+    int device = 0;
+    void* d_bvh = nullptr;
+    size_t bvhVec4 = 0;
+    uint32_t P = 0;
+    bool bvhFinite = false;
+    int variant = rts::V_STRAIGHT;
+    int swizzle = 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // staging for the host-pointer entries
+    void* d_in = nullptr; size_t inBytes = 0;
+    void* d_out = nullptr; size_t outBytes = 0;
+    std::string lastKernel;
+    uint64_t launches = 0;
+};
+
+namespace {
+
+inline int hipStatus(hipError_t e) { return e == hipSuccess ? RTS_OK : RTS_ERR_HIP + (int)e; }
+#define RTS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipStatus(e_); } while (0)
+
+int ensure(void** p, size_t* have, size_t want) {
+    if (*have >= want && *p) return RTS_OK;
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; *have = 0; if (e != hipSuccess) return hipStatus(e); }
+    hipError_t e = hipMalloc(p, want ? want : 16);
+    if (e != hipSuccess) { *p = nullptr; return hipStatus(e); }
+    *have = want;
+    return RTS_OK;
+}
+
+int fillParams(rts_ctx* ctx, TraceParams& p) {
+    memset(&p, 0, sizeof(p));
+    if (!ctx->d_bvh) return RTS_ERR_NO_BVH;
+    p.bvh = ctx->d_bvh;
+    p.bvhBytes = (uint32_t)(ctx->bvhVec4 * 16);
+    p.bvhFinite = ctx->bvhFinite ? 1u : 0u;
+    return RTS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rts_status_string(int s) {
+    switch (s) {
+    case RTS_OK: return "ok";
+    case RTS_ERR_INVALID_ARG: return "invalid argument";
+    case RTS_ERR_CAPACITY: return "output capacity too small";
+    case RTS_ERR_NONFINITE: return "non-finite vertex";
+    case RTS_ERR_NO_BVH: return "no BVH set on context";
+    case RTS_ERR_BAD_BVH: return "packed BVH failed validation";
+    default: break;
+    }
+    if (s >= RTS_ERR_HIP) return hipGetErrorString((hipError_t)(s - RTS_ERR_HIP));
+    return "unknown";
+}
+
+size_t rts_bvh_packed_count(uint32_t P) { return P ? (size_t)5 * P - 2 : 0; }
+size_t rts_bvh_node_count(uint32_t P) { return P ? (size_t)2 * P - 1 : 0; }
+
+int rts_bvh_build_ex(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                     uint32_t sah_prim_limit, int threads, rts_vec4u* out, size_t cap, rts_bvh_node* out_nodes) {
+    if (!vertices || !indices || !out || P == 0) return RTS_ERR_INVALID_ARG;
+    if (cap < rts_bvh_packed_count(P)) return RTS_ERR_CAPACITY;
+    try {
+        rts::BVHBuilder b;
+        b.sahPrimLimit = sah_prim_limit;
+        b.threads = threads;
+        if (!b.build(vertices, stride, indices, P)) return b.lastError ? b.lastError : RTS_ERR_INVALID_ARG;
+        memcpy(out, b.m_packedNodes.data(), b.m_packedNodes.size() * sizeof(rts_vec4u));
+        if (out_nodes) memcpy(out_nodes, b.m_nodes.data(), b.m_nodes.size() * sizeof(rts_bvh_node));
+    } catch (...) {
+        return RTS_ERR_INVALID_ARG;
+    }
+    return RTS_OK;
+}
+
+int rts_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                  rts_vec4u* out, size_t cap, rts_bvh_node* out_nodes) {
+    return rts_bvh_build_ex(vertices, stride, indices, P, 1000000u, 0, out, cap, out_nodes);
+}
+
+int rts_bvh_validate(const rts_vec4u* packed, size_t count, uint32_t* prim_count_out) {
+    if (!packed || count < 3 || (count + 2) % 5 != 0) return packed ? RTS_ERR_BAD_BVH : RTS_ERR_INVALID_ARG;
+    const uint64_t P = (count + 2) / 5, N = 2 * P - 1;
+    if (P > 0x33333333ull) return RTS_ERR_BAD_BVH;
+    for (uint64_t i = 0; i < N; ++i) {
+        const rts_vec4u& a = packed[2 * i];
+        const rts_vec4u& b = packed[2 * i + 1];
+        if (b.d != 0xFFFFFFFFu && !(b.d > i && b.d < N)) return RTS_ERR_BAD_BVH;      // strictly forward
+        if (a.d == 0xFFFFFFFFu) { if (i + 1 >= N) return RTS_ERR_BAD_BVH; }            // inner: i+1 exists
+        else if (a.d < 2 * N || a.d >= 2 * N + P) return RTS_ERR_BAD_BVH;               // leaf: tail pointer
+    }
+    if (prim_count_out) *prim_count_out = (uint32_t)P;
+    return RTS_OK;
+}
+
+int rts_device_count(int* count) {
+    if (!count) return RTS_ERR_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return hipStatus(e);
+}
+
+int rts_ctx_create(int device, rts_ctx** out) {
+    if (!out) return RTS_ERR_INVALID_ARG;
+    *out = nullptr;
+    RTS_HIP(hipSetDevice(device));
+    rts_ctx* c = new (std::nothrow) rts_ctx();
+    if (!c) return RTS_ERR_INVALID_ARG;
+    c->device = device;
+    hipError_t e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) { delete c; return hipStatus(e); }
+    *out = c;
+    return RTS_OK;
+}
+
+int rts_ctx_destroy(rts_ctx* c) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->d_bvh) (void)hipFree(c->d_bvh);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return RTS_OK;
+}
+
+int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
+    if (!c || !packed) return RTS_ERR_INVALID_ARG;
+    uint32_t P = 0;
+    int s = rts_bvh_validate(packed, count, &P);
+    if (s != RTS_OK) return s;
+    const uint64_t N = 2ull * P - 1;
+    bool finite = true;
+    for (uint64_t i = 0; i < 2 * N + P && finite; ++i) {
+        float f[3]; memcpy(f, &packed[i], 12);
+        finite = std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2]);
+    }
+    RTS_HIP(hipSetDevice(c->device));
+    if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
+    RTS_HIP(hipMalloc(&c->d_bvh, count * 16));
+    RTS_HIP(hipMemcpy(c->d_bvh, packed, count * 16, hipMemcpyHostToDevice));
+    c->bvhVec4 = count; c->P = P; c->bvhFinite = finite;
+    return RTS_OK;
+}
+
+int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
+    if (!c || !key) return RTS_ERR_INVALID_ARG;
+    if (!strcmp(key, "kernel")) { if (value < 0 || value >= rts::V_COUNT) return RTS_ERR_INVALID_ARG; c->variant = value; return RTS_OK; }
+    if (!strcmp(key, "xcd_swizzle")) { c->swizzle = value ? 1 : 0; return RTS_OK; }
+    return RTS_ERR_INVALID_ARG;
+}
+
+int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
+    if (!c || !key || !value) return RTS_ERR_INVALID_ARG;
+    if (!strcmp(key, "kernel")) { *value = c->variant; return RTS_OK; }
+    if (!strcmp(key, "xcd_swizzle")) { *value = c->swizzle; return RTS_OK; }
+    if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
+    if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
+    return RTS_ERR_INVALID_ARG;
+}
+
+int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_light* light,
+                                 const float* d_positions, uint32_t W, uint32_t H,
+                                 uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream) {
+    if (!c || !k || !d_positions || !d_mask || W == 0 || H == 0 || row_begin > row_end || row_end > H)
+        return RTS_ERR_INVALID_ARG;
+    if (light && (light->type > RTS_LIGHT_POINT || light->nsamples > 64)) return RTS_ERR_INVALID_ARG;
+    TraceParams p;
+    int s = fillParams(c, p);
+    if (s != RTS_OK) return s;
+    if (row_begin == row_end) return RTS_OK;
+    RTS_HIP(hipSetDevice(c->device));
+    p.positions = (const float4*)d_positions;
+    p.mask = d_mask;
+    p.W = W; p.H = H; p.rowBegin = row_begin; p.rowEnd = row_end;
+    p.blocksX = (W + 15) / 16;
+    p.blocksY = (row_end - row_begin + 15) / 16;
+    p.nBlocks = p.blocksX * p.blocksY;
+    p.swizzle = c->swizzle ? 1u : 0u;
+    p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
+    for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
+    if (light) {
+        p.lightType = light->type;
+        p.nsamples = light->nsamples > 1 ? light->nsamples : 1;
+        for (int i = 0; i < 3; ++i) p.light[i] = light->xyz[i];
+        if (p.nsamples > 1) memcpy(p.offsets, light->offsets, sizeof(float) * 4 * p.nsamples);
+    } else {
+        p.lightType = RTS_LIGHT_DIRECTIONAL;
+        p.nsamples = 1;
+        for (int i = 0; i < 3; ++i) p.light[i] = k->lightDirection[i];
+    }
+    c->lastKernel = rts::kernelName(c->variant, true);
+    ++c->launches;
+    return hipStatus(rts::launchShadowMask(c->variant, p, (hipStream_t)stream));
+}
+
+int rts_trace_shadow_mask(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* positions,
+                          uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, uint8_t* mask) {
+    if (!c || !k || !positions || !mask || W == 0 || H == 0 || row_begin > row_end || row_end > H)
+        return RTS_ERR_INVALID_ARG;
+    if (!c->d_bvh) return RTS_ERR_NO_BVH;
+    if (row_begin == row_end) return RTS_OK;
+    RTS_HIP(hipSetDevice(c->device));
+    // Only the stripe travels: the device buffers hold rows [row_begin,row_end) as a frame of their own.
+    const uint32_t rows = row_end - row_begin;
+    const size_t inB = (size_t)rows * W * 16, outB = (size_t)rows * W;
+    int s = ensure(&c->d_in, &c->inBytes, inB);
+    if (s == RTS_OK) s = ensure(&c->d_out, &c->outBytes, outB);
+    if (s != RTS_OK) return s;
+    RTS_HIP(hipMemcpy(c->d_in, positions + (size_t)row_begin * W * 4, inB, hipMemcpyHostToDevice));
+    s = rts_trace_shadow_mask_device(c, k, light, (const float*)c->d_in, W, rows, 0, rows, (uint8_t*)c->d_out, nullptr);
+    if (s != RTS_OK) return s;
+    RTS_HIP(hipMemcpy(mask + (size_t)row_begin * W, c->d_out, outB, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+int rts_trace_rays_device(rts_ctx* c, const rts_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
+    if (!c || (n && (!d_rays || !d_out))) return RTS_ERR_INVALID_ARG;
+    TraceParams p;
+    int s = fillParams(c, p);
+    if (s != RTS_OK) return s;
+    if (n == 0) return RTS_OK;
+    RTS_HIP(hipSetDevice(c->device));
+    p.rays = d_rays; p.out = d_out; p.nrays = n;
+    c->lastKernel = rts::kernelName(c->variant, false);
+    ++c->launches;
+    return hipStatus(rts::launchTraceRays(c->variant, p, (hipStream_t)stream));
+}
+
+int rts_trace_rays(rts_ctx* c, const rts_ray* rays, size_t n, uint8_t* out) {
+    if (!c || (n && (!rays || !out))) return RTS_ERR_INVALID_ARG;
+    if (!c->d_bvh) return RTS_ERR_NO_BVH;
+    if (n == 0) return RTS_OK;
+    RTS_HIP(hipSetDevice(c->device));
+    int s = ensure(&c->d_in, &c->inBytes, n * sizeof(rts_ray));
+    if (s == RTS_OK) s = ensure(&c->d_out, &c->outBytes, n);
+    if (s != RTS_OK) return s;
+    RTS_HIP(hipMemcpy(c->d_in, rays, n * sizeof(rts_ray), hipMemcpyHostToDevice));
+    s = rts_trace_rays_device(c, (const rts_ray*)c->d_in, n, (uint8_t*)c->d_out, nullptr);
+    if (s != RTS_OK) return s;
+    RTS_HIP(hipMemcpy(out, c->d_out, n, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+int rts_device_malloc(rts_ctx* c, void** p, size_t bytes) {
+    if (!c || !p) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMalloc(p, bytes ? bytes : 16));
+    return RTS_OK;
+}
+int rts_device_free(rts_ctx* c, void* p) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipFree(p));
+    return RTS_OK;
+}
+int rts_memcpy_h2d(rts_ctx* c, void* d, const void* s, size_t bytes) {
+    if (!c || !d || !s) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMemcpy(d, s, bytes, hipMemcpyHostToDevice));
+    return RTS_OK;
+}
+int rts_memcpy_d2h(rts_ctx* c, void* d, const void* s, size_t bytes) {
+    if (!c || !d || !s) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+int rts_stream_synchronize(rts_ctx* c, void* stream) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RTS_OK;
+}
+int rts_timer_begin(rts_ctx* c, void* stream) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipEventRecord(c->ev0, (hipStream_t)stream));
+    return RTS_OK;
+}
+int rts_timer_end(rts_ctx* c, void* stream) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipEventRecord(c->ev1, (hipStream_t)stream));
+    return RTS_OK;
+}
+int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
+    if (!c || !ms) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipEventSynchronize(c->ev1));
+    RTS_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RTS_OK;
+}
+const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel.c_str() : ""; }
+
+} // extern "C"

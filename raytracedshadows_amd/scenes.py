@@ -1,0 +1,235 @@
+"""Harness: seeded procedural stand-ins for the scenes BASELINE.json names.
+
+No mesh assets exist offline, so each config gets a generator that emits an indexed
+triangle mesh which is then written as real ``.obj`` text and read back through the OBJ reader
+(``rtsh_obj_load``), i.e. the same ingest route the reference uses
+(``Source/RayTracedShadows.cpp:764-824``).
+
+=========  =====================================  ==========  =========================
+name       stand-in for                            triangles   BASELINE.json config
+=========  =====================================  ==========  =========================
+cornell    Cornell-box-scale OBJ                   1 024       configs[0]  256 x 256
+atrium     Sponza-class OBJ                        ~250 k      configs[1]  1920 x 1080
+city       ~1M-tri OBJ, below the builder switch   999 488     configs[2-4]  3840 x 2160
+city_big   same, above 1 000 000 primitives        1 034 288   builder's median-split branch
+=========  =====================================  ==========  =========================
+
+Camera and light follow the reference's defaults where it has any (eye = bbox.max + 2 looking at the
+bbox centre, fov 1.0 rad: ``Source/RayTracedShadows.cpp:238-242``; directional light
+normalize(1,1,1): ``cpp:245``); the in-scene point light is this harness's choice.
+"""
+import os
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------
+# mesh pieces (float64 maths, cast to float32 once at the end)
+# ------------------------------------------------------------------------------------------------
+def _grid(origin, du, dv, nu, nv):
+    """(nu x nv) quads spanning origin + s*du + t*dv, s,t in [0,1]; two triangles per quad."""
+    s = np.linspace(0.0, 1.0, nu + 1)
+    t = np.linspace(0.0, 1.0, nv + 1)
+    S, T = np.meshgrid(s, t, indexing="xy")
+    verts = (np.asarray(origin)[None, None, :] + S[..., None] * np.asarray(du)[None, None, :]
+             + T[..., None] * np.asarray(dv)[None, None, :]).reshape(-1, 3)
+    i = np.arange(nu)[None, :] + (nu + 1) * np.arange(nv)[:, None]
+    i = i.reshape(-1)
+    faces = np.stack([np.stack([i, i + 1, i + nu + 2], 1), np.stack([i, i + nu + 2, i + nu + 1], 1)], 1).reshape(-1, 3)
+    return verts, faces
+
+
+def _box(lo, hi, sub=1):
+    """Axis-aligned box, each face a sub x sub grid."""
+    lo = np.asarray(lo, float)
+    hi = np.asarray(hi, float)
+    d = hi - lo
+    ex, ey, ez = np.array([d[0], 0, 0]), np.array([0, d[1], 0]), np.array([0, 0, d[2]])
+    parts = [(lo, ex, ey), (lo + ez, ey, ex), (lo, ey, ez), (lo + ex, ez, ey), (lo, ez, ex), (lo + ey, ex, ez)]
+    return _merge([_grid(o, a, b, sub, sub) for (o, a, b) in parts])
+
+
+def _boxes_fast(lo, hi):
+    """Many 12-triangle boxes at once: lo/hi are (n,3)."""
+    n = lo.shape[0]
+    corners = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], float)
+    verts = (lo[:, None, :] + corners[None, :, :] * (hi - lo)[:, None, :]).reshape(-1, 3)
+    quad = np.array([[0, 3, 2, 1], [4, 5, 6, 7], [0, 1, 5, 4], [2, 3, 7, 6], [1, 2, 6, 5], [0, 4, 7, 3]])
+    tri = np.concatenate([quad[:, [0, 1, 2]], quad[:, [0, 2, 3]]], 0)
+    faces = (tri[None, :, :] + 8 * np.arange(n)[:, None, None]).reshape(-1, 3)
+    return verts, faces
+
+
+def _cylinder(center, radius, y0, y1, sides, segments):
+    a = np.linspace(0.0, 2.0 * np.pi, sides, endpoint=False)
+    ys = np.linspace(y0, y1, segments + 1)
+    ring = np.stack([center[0] + radius * np.cos(a), np.zeros_like(a), center[1] + radius * np.sin(a)], 1)
+    verts = np.repeat(ring[None, :, :], segments + 1, 0)
+    verts[:, :, 1] = ys[:, None]
+    verts = verts.reshape(-1, 3)
+    i = (np.arange(sides)[None, :] + sides * np.arange(segments)[:, None]).reshape(-1)
+    j = ((np.arange(sides) + 1) % sides)[None, :] + sides * np.arange(segments)[:, None]
+    j = j.reshape(-1)
+    faces = np.stack([np.stack([i, j, j + sides], 1), np.stack([i, j + sides, i + sides], 1)], 1).reshape(-1, 3)
+    return verts, faces
+
+
+def _merge(parts):
+    verts, faces, base = [], [], 0
+    for v, f in parts:
+        verts.append(v)
+        faces.append(f + base)
+        base += v.shape[0]
+    return np.concatenate(verts, 0), np.concatenate(faces, 0)
+
+
+def _value_noise(x, z, seed, cells):
+    """Smooth lattice noise in [0,1] from a seeded table (bilinear + smoothstep)."""
+    rs = np.random.RandomState(seed)
+    table = rs.random_sample((cells + 2, cells + 2))
+    xi = np.floor(x).astype(int) % cells
+    zi = np.floor(z).astype(int) % cells
+    fx = x - np.floor(x)
+    fz = z - np.floor(z)
+    fx = fx * fx * (3 - 2 * fx)
+    fz = fz * fz * (3 - 2 * fz)
+    a, b = table[zi, xi], table[zi, xi + 1]
+    c, d = table[zi + 1, xi], table[zi + 1, xi + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fz) + (c * (1 - fx) + d * fx) * fz
+
+
+# ------------------------------------------------------------------------------------------------
+# scenes
+# ------------------------------------------------------------------------------------------------
+def cornell(seed=1):
+    """Room of five walls (8x8 quads each) + two boxes (4x4 quads per face): 1 024 triangles."""
+    del seed  # geometry is fixed; the argument keeps the generator signature uniform
+    k = 8
+    walls = [
+        _grid([0, 0, 0], [10, 0, 0], [0, 0, 10], k, k),      # floor
+        _grid([0, 10, 0], [0, 0, 10], [10, 0, 0], k, k),     # ceiling
+        _grid([0, 0, 0], [0, 10, 0], [10, 0, 0], k, k),      # back
+        _grid([0, 0, 0], [0, 0, 10], [0, 10, 0], k, k),      # left
+        _grid([10, 0, 0], [0, 10, 0], [0, 0, 10], k, k),     # right
+    ]
+    boxes = [_box([1.5, 0, 1.5], [4.5, 6, 4.5], 4), _box([5.5, 0, 5], [8.5, 3, 8], 4)]
+    v, f = _merge(walls + boxes)
+    return _finish("cornell", v, f, light_point=[5.0, 9.5, 5.0])
+
+
+def atrium(seed=2):
+    """Bumpy floor, flat ceiling with a skylight gap, 12x12 round columns, scattered crates: ~250 k."""
+    rs = np.random.RandomState(seed)
+    n = 200
+    fv, ff = _grid([0, 0, 0], [120, 0, 0], [0, 0, 120], n, n)                      # 80 000
+    fv[:, 1] = 0.35 * _value_noise(fv[:, 0] / 6.0, fv[:, 2] / 6.0, seed, 32)
+    parts = [(fv, ff)]
+    parts.append(_grid([0, 30, 0], [0, 0, 120], [50, 0, 0], 40, 40))                # ceiling west   3 200
+    parts.append(_grid([70, 30, 0], [0, 0, 120], [50, 0, 0], 40, 40))               # ceiling east   3 200
+    for ix in range(12):                                                           # 144 x 960 = 138 240
+        for iz in range(12):
+            parts.append(_cylinder([5 + 10 * ix, 5 + 10 * iz], 0.9 + 0.3 * rs.random_sample(), 0.0, 30.0, 24, 20))
+    m = 2113                                                                        # crates  25 356
+    c = np.stack([rs.random_sample(m) * 116 + 2, np.zeros(m), rs.random_sample(m) * 116 + 2], 1)
+    s = 0.3 + rs.random_sample((m, 3)) * np.array([1.5, 2.5, 1.5])
+    lo = c - s * np.array([0.5, 0.0, 0.5])
+    parts.append(_boxes_fast(lo, lo + s))
+    v, f = _merge(parts)
+    return _finish("atrium", v, f, light_point=[60.0, 26.0, 60.0])
+
+
+def _city(name, seed, boxes):
+    rs = np.random.RandomState(seed)
+    n = 512
+    tv, tf = _grid([0, 0, 0], [400, 0, 0], [0, 0, 400], n, n)                      # 524 288
+    h = 10.0 * _value_noise(tv[:, 0] / 40.0, tv[:, 2] / 40.0, seed, 16) \
+        + 1.5 * _value_noise(tv[:, 0] / 7.0, tv[:, 2] / 7.0, seed + 1, 64)
+    tv[:, 1] = h
+    c = np.stack([rs.random_sample(boxes) * 392 + 4, rs.random_sample(boxes) * 392 + 4], 1)
+    foot = 1.0 + rs.random_sample((boxes, 2)) * 5.0
+    tall = 2.0 + rs.random_sample(boxes) ** 3 * 45.0
+    base = 10.0 * _value_noise(c[:, 0] / 40.0, c[:, 1] / 40.0, seed, 16) - 1.0
+    lo = np.stack([c[:, 0] - foot[:, 0] / 2, base, c[:, 1] - foot[:, 1] / 2], 1)
+    hi = np.stack([c[:, 0] + foot[:, 0] / 2, base + tall, c[:, 1] + foot[:, 1] / 2], 1)
+    v, f = _merge([(tv, tf), _boxes_fast(lo, hi)])
+    return _finish(name, v, f, light_point=[140.0, 75.0, 260.0])
+
+
+def city(seed=3):
+    """Displaced 512x512 terrain + 39 600 buildings: 999 488 triangles (full-SAH builder branch)."""
+    return _city("city", seed, 39600)
+
+
+def city_big(seed=3):
+    """Same with 42 500 buildings: 1 034 288 triangles (> 1 000 000: median-split at the root)."""
+    return _city("city_big", seed, 42500)
+
+
+def terrain(n=23, seed=7):
+    """Small sin-free bumpy grid with many equal centroids per axis (sort-tie stress): 2*n*n tris."""
+    v, f = _grid([0, 0, 0], [float(n), 0, 0], [0, 0, float(n)], n, n)
+    v[:, 1] = 2.0 * _value_noise(v[:, 0] / 4.0, v[:, 2] / 4.0, seed, 8)
+    return _finish(f"terrain{n}", v, f, light_point=[n * 0.5, 6.0, n * 0.5])
+
+
+SCENES = {"cornell": cornell, "atrium": atrium, "city": city, "city_big": city_big}
+
+
+# ------------------------------------------------------------------------------------------------
+# scene record, OBJ text, flat expansion, camera
+# ------------------------------------------------------------------------------------------------
+class Scene:
+    def __init__(self, name, verts, faces, light_point):
+        self.name = name
+        self.verts = verts          # float32 [nv, 3]
+        self.faces = faces          # uint32  [nt, 3]
+        self.bbox_min = verts.min(0)
+        self.bbox_max = verts.max(0)
+        self.light_point = np.asarray(light_point, np.float32)
+        self.light_direction = (np.ones(3) / np.sqrt(3.0)).astype(np.float32)   # cpp:245
+        # camera defaults of the reference (cpp:238-242)
+        self.eye = (self.bbox_max + np.float32(2.0)).astype(np.float32)
+        self.target = ((self.bbox_min + self.bbox_max) * np.float32(0.5)).astype(np.float32)
+        self.fovy = 1.0
+
+    @property
+    def triangle_count(self):
+        return int(self.faces.shape[0])
+
+    def flat(self):
+        """loadModel's expansion (cpp:783-824): 8 floats per vertex, ``indices[i] = i``."""
+        p = self.verts[self.faces.reshape(-1)]
+        out = np.zeros((p.shape[0], 8), np.float32)
+        out[:, :3] = p
+        return out, np.arange(p.shape[0], dtype=np.uint32)
+
+    def write_obj(self, path):
+        """Real OBJ text; %.9g round-trips every float32 exactly through a correct decimal reader."""
+        with open(path, "w") as fh:
+            fh.write(f"# {self.name}: {self.verts.shape[0]} vertices, {self.faces.shape[0]} triangles\n")
+            np.savetxt(fh, self.verts.astype(np.float64), fmt="v %.9g %.9g %.9g")
+            np.savetxt(fh, self.faces.astype(np.int64) + 1, fmt="f %d %d %d")
+        return path
+
+
+def _finish(name, v, f, light_point):
+    return Scene(name, np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.uint32), light_point)
+
+
+def jitter_offsets(n, radius, seed=11):
+    """n seeded offsets inside a sphere of `radius` (area-light samples for the 16-spp config)."""
+    rs = np.random.RandomState(seed)
+    out = np.zeros((n, 4), np.float32)
+    k = 0
+    while k < n:
+        p = rs.random_sample(3) * 2.0 - 1.0
+        if p @ p <= 1.0:
+            out[k, :3] = (p * radius).astype(np.float32)
+            k += 1
+    return out
+
+
+def cache_dir():
+    d = os.environ.get("RTS_SCENE_CACHE", "/tmp/rts_scenes")
+    os.makedirs(d, exist_ok=True)
+    return d
