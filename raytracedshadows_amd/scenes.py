@@ -135,34 +135,54 @@ def atrium(seed=2):
     lo = c - s * np.array([0.5, 0.0, 0.5])
     parts.append(_boxes_fast(lo, lo + s))
     v, f = _merge(parts)
-    return _finish("atrium", v, f, light_point=[60.0, 26.0, 60.0])
+    sc = _finish("atrium", v, f, light_point=[60.0, 26.0, 60.0])
+    # the reference's default camera (bbox.max + 2) would look at the roof from outside: stand inside
+    sc.eye = np.array([6.0, 11.0, 9.0], np.float32)
+    sc.target = np.array([80.0, 7.0, 95.0], np.float32)
+    return sc
 
 
-def _city(name, seed, boxes):
+def _instances(unit, lo, hi):
+    """One copy of the unit-cube mesh `unit` per (lo, hi) pair."""
+    uv, uf = unit
+    verts = (lo[:, None, :] + uv[None, :, :] * (hi - lo)[:, None, :]).reshape(-1, 3)
+    faces = (uf[None, :, :] + uv.shape[0] * np.arange(lo.shape[0])[:, None, None]).reshape(-1, 3)
+    return verts, faces
+
+
+def _city(name, seed, buildings):
+    """1000 x 1000 displaced terrain (512 x 512 quads) + `buildings` towers of 48 triangles each."""
     rs = np.random.RandomState(seed)
-    n = 512
-    tv, tf = _grid([0, 0, 0], [400, 0, 0], [0, 0, 400], n, n)                      # 524 288
-    h = 10.0 * _value_noise(tv[:, 0] / 40.0, tv[:, 2] / 40.0, seed, 16) \
-        + 1.5 * _value_noise(tv[:, 0] / 7.0, tv[:, 2] / 7.0, seed + 1, 64)
-    tv[:, 1] = h
-    c = np.stack([rs.random_sample(boxes) * 392 + 4, rs.random_sample(boxes) * 392 + 4], 1)
-    foot = 1.0 + rs.random_sample((boxes, 2)) * 5.0
-    tall = 2.0 + rs.random_sample(boxes) ** 3 * 45.0
-    base = 10.0 * _value_noise(c[:, 0] / 40.0, c[:, 1] / 40.0, seed, 16) - 1.0
+    n, size = 512, 1000.0
+
+    def ground(x, z):
+        return 25.0 * _value_noise(x / 100.0, z / 100.0, seed, 16) + 3.0 * _value_noise(x / 15.0, z / 15.0, seed + 1, 96)
+
+    tv, tf = _grid([0, 0, 0], [size, 0, 0], [0, 0, size], n, n)                    # 524 288
+    tv[:, 1] = ground(tv[:, 0], tv[:, 2])
+    c = np.stack([rs.random_sample(buildings) * (size - 20) + 10, rs.random_sample(buildings) * (size - 20) + 10], 1)
+    foot = 3.0 + rs.random_sample((buildings, 2)) * 7.0
+    tall = 4.0 + rs.random_sample(buildings) ** 3 * 70.0
+    base = ground(c[:, 0], c[:, 1]) - 2.0
     lo = np.stack([c[:, 0] - foot[:, 0] / 2, base, c[:, 1] - foot[:, 1] / 2], 1)
     hi = np.stack([c[:, 0] + foot[:, 0] / 2, base + tall, c[:, 1] + foot[:, 1] / 2], 1)
-    v, f = _merge([(tv, tf), _boxes_fast(lo, hi)])
-    return _finish(name, v, f, light_point=[140.0, 75.0, 260.0])
+    v, f = _merge([(tv, tf), _instances(_box([0, 0, 0], [1, 1, 1], 2), lo, hi)])
+    sc = _finish(name, v, f, light_point=[420.0, 300.0, 560.0])
+    # the reference's default (bbox.max + 2 -> bbox centre) leaves half of a 4K frame as sky; come
+    # closer and aim at the ground so that ~85 % of the pixels carry a geometry ray
+    sc.eye = np.array([760.0, 170.0, 770.0], np.float32)
+    sc.target = np.array([400.0, -120.0, 390.0], np.float32)
+    return sc
 
 
 def city(seed=3):
-    """Displaced 512x512 terrain + 39 600 buildings: 999 488 triangles (full-SAH builder branch)."""
-    return _city("city", seed, 39600)
+    """Displaced 512x512 terrain + 9 900 towers: 999 488 triangles (full-SAH builder branch)."""
+    return _city("city", seed, 9900)
 
 
 def city_big(seed=3):
-    """Same with 42 500 buildings: 1 034 288 triangles (> 1 000 000: median-split at the root)."""
-    return _city("city_big", seed, 42500)
+    """Same with 10 625 towers: 1 034 288 triangles (> 1 000 000: median-split at the root)."""
+    return _city("city_big", seed, 10625)
 
 
 def terrain(n=23, seed=7):

@@ -1,0 +1,71 @@
+"""Harness: turns a BASELINE.json config into the inputs of the shadow dispatch.
+
+scene generator -> real .obj text -> OBJ reader (loadModel semantics) -> BVHBuilder.build ->
+camera -> G-buffer positions -> RayTracingConstants + light.  Nothing here is timed as part of the
+hot path; both the GPU kernels and the CPU oracle consume the arrays this produces.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import api, scenes
+
+#: BASELINE.json "configs", in order.  (scene, W, H, light kind, samples per pixel)
+CONFIGS = {
+    "cornell_256": ("cornell", 256, 256, "point", 1),         # configs[0]
+    "atrium_1080p": ("atrium", 1920, 1080, "point", 1),       # configs[1]
+    "city_4k": ("city", 3840, 2160, "point", 1),              # configs[2]  (headline; [3] = same, striped)
+    "city_4k_soft16": ("city", 3840, 2160, "point", 16),      # configs[4]
+}
+
+
+class Workload:
+    pass
+
+
+def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None):
+    say = log or (lambda *a: None)
+    wl = Workload()
+    t0 = time.time()
+    sc = scenes.SCENES[scene_name]() if isinstance(scene_name, str) else scene_name
+    say(f"scene {sc.name}: {sc.triangle_count} triangles generated in {time.time() - t0:.2f}s")
+    if via_obj:
+        t0 = time.time()
+        path = os.path.join(scenes.cache_dir(), f"{sc.name}.obj")
+        sc.write_obj(path)
+        verts, indices, lo, hi = api.obj_load(path)
+        say(f"obj written + parsed in {time.time() - t0:.2f}s ({os.path.getsize(path) / 1e6:.1f} MB)")
+    else:
+        verts, indices = sc.flat()
+    prim_count = verts.shape[0] // 3
+    t0 = time.time()
+    builder = api.BVHBuilder(threads=threads).build(verts, 8, indices, prim_count)
+    wl.build_seconds = time.time() - t0
+    say(f"BVH built in {wl.build_seconds:.2f}s ({builder.m_packedNodes.nbytes / 1e6:.1f} MB packed)")
+    t0 = time.time()
+    positions, hits = api.primary_positions(builder.m_packedNodes, sc.eye, sc.target, sc.fovy, W, H, threads)
+    say(f"G-buffer positions {W}x{H} in {time.time() - t0:.2f}s ({hits / (W * H) * 100:.1f}% of pixels hit geometry)")
+
+    wl.scene = sc
+    wl.W, wl.H, wl.spp = W, H, spp
+    wl.prim_count = prim_count
+    wl.vertices, wl.indices = verts, indices
+    wl.packed = builder.m_packedNodes
+    wl.nodes = builder.m_nodes
+    wl.positions = positions
+    wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
+    if light == "directional":
+        wl.light = None if spp <= 1 else api.Light.make(api.Light.DIRECTIONAL, sc.light_direction,
+                                                        scenes.jitter_offsets(spp, 0.05))
+    else:
+        radius = 0.01 * float(np.linalg.norm(sc.bbox_max - sc.bbox_min))
+        wl.light = api.Light.make(api.Light.POINT, sc.light_point,
+                                  scenes.jitter_offsets(spp, radius) if spp > 1 else None)
+    wl.rays = W * H * max(1, spp)
+    return wl
+
+
+def prepare_config(name, **kw):
+    scene, W, H, light, spp = CONFIGS[name]
+    return prepare(scene, W, H, light=light, spp=spp, **kw)
