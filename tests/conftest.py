@@ -19,5 +19,6 @@ def _built():
     if not os.path.exists(os.path.join(ROOT, "raytracedshadows_amd", "librts.so")):
         build.build_product()
     if not os.path.exists(os.path.join(ROOT, "oracle", "librts_oracle.so")):
-        build.build_oracle()
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
     yield

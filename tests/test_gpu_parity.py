@@ -1,0 +1,268 @@
+"""GPU (MI355X): the HIP path, called through the C ABI of librts.so, against the CPU oracle.
+
+Bar: bit-exact -- every mask byte equal -- for every kernel variant, on every BASELINE.json config at
+its full size, on the committed fixtures, under row striping, and on the edge cases of SURVEY.md
+Appendix B (axis-parallel rays, NaN/Inf, degenerate triangles, denormals, ragged frame sizes)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracedshadows_amd import api, partition, scenes, workloads
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert api.device_count() >= 1, "no GPU visible: the shadow path has no CPU fallback"
+    c = api.ShadowContext(0)
+    yield c
+    c.close()
+
+
+def _variants(ctx):
+    return list(range(ctx.get_option("kernel_count")))
+
+
+def _check_workload(ctx, wl, variants=None, swizzles=(0,)):
+    want, V, L = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                    oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+    ctx.set_bvh(wl.packed)
+    for sw in swizzles:
+        ctx.set_option("xcd_swizzle", sw)
+        for v in (variants if variants is not None else _variants(ctx)):
+            ctx.set_option("kernel", v)
+            got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+            bad = int((got != want).sum())
+            assert bad == 0, f"kernel {v} swizzle {sw}: {bad}/{want.size} bytes differ"
+    ctx.set_option("xcd_swizzle", 0)
+    return want
+
+
+@pytest.mark.parametrize("name", ["cornell_128", "terrain_96"])
+def test_committed_fixtures(ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    H, W = g["mask_dir"].shape
+    k = api.RayTracingConstants()
+    arr = g["constants"]
+    for i in range(4):
+        k.cameraPosition[i], k.cameraDirection[i] = arr[i], arr[4 + i]
+        k.lightDirection[i], k.renderTargetSize[i] = arr[8 + i], arr[12 + i]
+    ctx.set_bvh(g["packed"])
+    for v in _variants(ctx):
+        ctx.set_option("kernel", v)
+        got = ctx.trace_shadow_mask(k, g["positions"], W, H)                     # light=None: the reference path
+        assert (got == g["mask_dir"]).all()
+        got = ctx.trace_shadow_mask(k, g["positions"], W, H, light=api.Light.make(api.Light.POINT, g["light_point"]))
+        assert (got == g["mask_point"]).all()
+
+
+def test_config0_cornell_256_point_and_directional(ctx):
+    wl = workloads.prepare_config("cornell_256")
+    _check_workload(ctx, wl, swizzles=(0, 1))
+    wl = workloads.prepare("cornell", 256, 256, light="directional")
+    _check_workload(ctx, wl)
+
+
+def test_config1_atrium_1080p_full_size(ctx):
+    _check_workload(ctx, workloads.prepare_config("atrium_1080p"), swizzles=(0, 1))
+
+
+def test_config2_city_4k_full_size(ctx):
+    wl = workloads.prepare_config("city_4k")
+    want = _check_workload(ctx, wl, swizzles=(0, 1))
+    assert 0.2 < want.mean() < 0.8                                                # a real mix of lit / occluded
+
+
+def test_config3_row_stripes_equal_full_frame(ctx):
+    """configs[3] on one device: the 2/4/8 stripe sets traced one after the other reproduce the frame."""
+    wl = workloads.prepare("atrium", 960, 540)
+    want = _check_workload(ctx, wl, variants=[0])
+    for n in (2, 4, 8):
+        for inter in (True, False):
+            out = np.full((wl.H, wl.W), 9, np.uint8)
+            for r in range(n):
+                for b, e in partition.stripe_rows(wl.H, n, r, 16, inter):
+                    ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light,
+                                          row_begin=b, row_end=e, out=out)
+            assert (out == want).all(), (n, inter)
+    out = np.full((wl.H, wl.W), 9, np.uint8)
+    ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light, row_begin=100, row_end=100, out=out)
+    assert (out == 9).all()                                                        # empty stripe: untouched
+
+
+def test_config4_soft_shadows_16_samples(ctx):
+    wl = workloads.prepare("cornell", 200, 120, spp=16)
+    want = _check_workload(ctx, wl)
+    assert want.max() == 16 and 0 < (want == 0).sum() and ((want > 0) & (want < 16)).sum() > 0   # penumbra exists
+    wl = workloads.prepare("city", 960, 540, spp=16)
+    _check_workload(ctx, wl, variants=[0, 1])
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (7, 5), (250, 131), (17, 300)])
+def test_ragged_frame_sizes(ctx, W, H):
+    """The reference has no bounds guard (comp:130, relies on robust access); ours must not touch
+    anything outside W x H."""
+    wl = workloads.prepare("cornell", W, H, via_obj=False)
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                    oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+    ctx.set_bvh(wl.packed)
+    d_pos = ctx.malloc(wl.positions.nbytes)
+    d_mask = ctx.malloc(W * H + 256)
+    guard = np.full(W * H + 256, 0xAB, np.uint8)
+    try:
+        for v in _variants(ctx):
+            ctx.set_option("kernel", v)
+            ctx.h2d(d_pos, wl.positions)
+            ctx.h2d(d_mask, guard)
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            ctx.synchronize()
+            got = np.zeros(W * H + 256, np.uint8)
+            ctx.d2h(got, d_mask)
+            assert (got[:W * H].reshape(H, W) == want).all()
+            assert (got[W * H:] == 0xAB).all()
+    finally:
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
+def _random_rays(n, seed, lo, hi):
+    rs = np.random.RandomState(seed)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = lo + rs.random_sample((n, 3)) * (hi - lo)
+    d = rs.standard_normal((n, 3))
+    rays[:, 4:7] = d
+    rays[:, 3] = np.where(rs.random_sample(n) < 0.5, 1e9, rs.random_sample(n) * 20)
+    return rays
+
+
+def test_generic_rays_including_nan_inf_and_axis_parallel(ctx):
+    sc = scenes.cornell()
+    verts, idx = sc.flat()
+    packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes
+    rays = _random_rays(200000, 3, sc.bbox_min - 2, sc.bbox_max + 2)
+    n = rays.shape[0]
+    # axis-parallel directions: exact zeros -> 1/0 = inf -> 0*inf = NaN on slab planes (Appendix B-3)
+    rays[0:40000, 4] = 0.0
+    rays[20000:60000, 5] = 0.0
+    rays[50000:70000, 6] = 0.0
+    # origins exactly on bounding planes and grid lines of the scene (walls at 0 and 10, grid step 1.25)
+    rays[0:70000, 0:3] = np.round(rays[0:70000, 0:3] / 1.25) * 1.25
+    rays[70000:70100, 0] = np.nan
+    rays[70100:70200, 5] = np.inf
+    rays[70200:70300, 1] = -np.inf
+    rays[70300:70400, 4:7] = 0.0                                                   # null direction
+    rays[70400:70500, 3] = np.nan                                                  # NaN tmax
+    rays[70500:70600, 4] = 1e-42                                                   # denormal direction -> 1/d = inf
+    rays[70600:70700, 3] = 0.0
+    want, _, _ = oracle.trace_rays(packed, rays)
+    ctx.set_bvh(packed)
+    for v in _variants(ctx):
+        ctx.set_option("kernel", v)
+        got = ctx.trace_rays(rays)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"kernel {v}: {bad.size} of {n} rays differ, first {bad[:5]}"
+    assert 0 < want.sum() < n
+
+
+def test_degenerate_and_denormal_triangles(ctx):
+    """Zero-area triangles 'hit' through the all-NaN rule (Appendix B-4); denormal edges must not be flushed."""
+    rs = np.random.RandomState(5)
+    P = 400
+    c = rs.random_sample((P, 1, 3)) * 10
+    tri = (c + (rs.random_sample((P, 3, 3)) - 0.5)).astype(np.float32)
+    tri[0:50, 1] = tri[0:50, 0]                                                    # v1 == v0
+    tri[50:100, 2] = tri[50:100, 1]                                                # v2 == v1 (sliver to a line)
+    tri[100:150] = tri[100:150, 0:1]                                               # all three equal (a point)
+    tiny = np.float32(1e-41)
+    tri[150:200, 1] = tri[150:200, 0] + np.array([tiny, 0, 0], np.float32)         # denormal-ish edge lengths
+    base = np.zeros((50, 3, 3), np.float32)
+    base[:, 1, 0] = tiny * 3
+    base[:, 2, 1] = tiny * 5
+    tri[200:250] = base                                                            # denormal triangles at the origin
+    verts = tri.reshape(-1, 3)
+    idx = np.arange(3 * P, dtype=np.uint32)
+    packed = api.BVHBuilder().build(verts, 3, idx, P).m_packedNodes
+    assert (packed == oracle.bvh_build(verts, 3, idx, P)).all()
+    rays = _random_rays(60000, 8, np.float32(-1), np.float32(11))
+    rays[:20000, 0:3] = verts[rs.randint(0, verts.shape[0], 20000)] - rays[:20000, 4:7] * 2   # aim at vertices
+    rays[20000:22000, 0:3] = 0.0
+    rays[20000:22000, 4:7] *= 1e-3
+    want, _, _ = oracle.trace_rays(packed, rays)
+    ctx.set_bvh(packed)
+    for v in _variants(ctx):
+        ctx.set_option("kernel", v)
+        got = ctx.trace_rays(rays)
+        assert (got == want).all(), f"kernel {v}: {(got != want).sum()} rays differ"
+
+
+def test_non_finite_bvh_takes_the_exact_path(ctx):
+    """A packed buffer from another producer may carry Inf boxes: the fast slab test must not be used."""
+    sc = scenes.terrain(9)
+    verts, idx = sc.flat()
+    packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes.copy()
+    f = packed.view(np.float32)
+    f[0, 0:3] = -np.inf                                                            # root box = everything
+    f[1, 0:3] = np.inf
+    rays = _random_rays(50000, 9, sc.bbox_min - 1, sc.bbox_max + 3)
+    want, _, _ = oracle.trace_rays(packed, rays)
+    ctx.set_bvh(packed)
+    assert ctx.get_option("bvh_finite") == 0
+    for v in _variants(ctx):
+        ctx.set_option("kernel", v)
+        assert (ctx.trace_rays(rays) == want).all()
+
+
+def test_single_triangle_and_two_triangle_trees(ctx):
+    for P in (1, 2):
+        v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 2], [1, 0, 2], [0, 1, 2]], np.float32)[:3 * P]
+        idx = np.arange(3 * P, dtype=np.uint32)
+        packed = api.BVHBuilder().build(v, 3, idx, P).m_packedNodes
+        rays = _random_rays(5000, P, np.float32(-1), np.float32(3))
+        rays[:1000, 4:7] = [0, 0, -1]
+        rays[:1000, 2] = 3
+        want, _, _ = oracle.trace_rays(packed, rays)
+        ctx.set_bvh(packed)
+        for k in _variants(ctx):
+            ctx.set_option("kernel", k)
+            assert (ctx.trace_rays(rays) == want).all()
+        assert want.min() == 0 and want.max() == 1
+
+
+def test_median_split_tree_traces_identically(ctx):
+    """A tree from the > 1 000 000-primitive branch of the builder (threshold lowered) through the kernels."""
+    sc = scenes.terrain(40)
+    verts, idx = sc.flat()
+    packed = api.BVHBuilder(sah_prim_limit=100).build(verts, 8, idx, sc.triangle_count).m_packedNodes
+    rays = _random_rays(100000, 4, sc.bbox_min - 1, sc.bbox_max + 4)
+    want, _, _ = oracle.trace_rays(packed, rays)
+    ctx.set_bvh(packed)
+    for k in _variants(ctx):
+        ctx.set_option("kernel", k)
+        assert (ctx.trace_rays(rays) == want).all()
+
+
+def test_error_behaviour(ctx):
+    fresh = api.ShadowContext(0)
+    try:
+        k = api.RayTracingConstants.make([0, 0, 0], [0, 1, 0], 8, 8)
+        with pytest.raises(api.RtsError) as e:
+            fresh.trace_shadow_mask(k, np.zeros((8, 8, 4), np.float32), 8, 8)
+        assert e.value.status == 4                                                 # RTS_ERR_NO_BVH
+        with pytest.raises(api.RtsError) as e:
+            fresh.set_bvh(np.zeros((7, 4), np.uint32))
+        assert e.value.status == 5
+        sc = scenes.terrain(5)
+        verts, idx = sc.flat()
+        fresh.set_bvh(api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes)
+        with pytest.raises(api.RtsError) as e:
+            fresh.trace_shadow_mask(k, np.zeros((8, 8, 4), np.float32), 8, 8, row_begin=5, row_end=9)
+        assert e.value.status == 1
+        with pytest.raises(api.RtsError):
+            fresh.set_option("no_such_option", 1)
+        assert fresh.trace_rays(np.zeros((0, 8), np.float32)).size == 0            # empty input is fine
+    finally:
+        fresh.close()
