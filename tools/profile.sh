@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun).  rocprofv3 kernel trace + separate PMC passes of bench.py.
+# usage: tools/profile.sh <tag> [bench args...]
+set -u
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 200 --warmup 20 $ARGS > $OUT/trace.json 2> $OUT/trace.err
+echo "trace rc=$?"
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_CVT" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
+  i=$((i+1))
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $REPO/bench.py --steps 5 --warmup 2 $ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
+  echo "pmc$i ($PMC) rc=$?"
+done
+cd $REPO
+python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
