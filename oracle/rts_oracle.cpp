@@ -471,3 +471,54 @@ int orc_max_threads(void) {
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Analysis helper (not a checker): for every 8x8 pixel tile of a frame, how many DISTINCT nodes
+// do its 64 rays visit (what a wave-uniform sweep in increasing DFS index would iterate over),
+// against the longest single ray (what a lane-per-ray loop iterates over) and the sum.
+// out[0]=tiles, out[1]=sum of union sizes, out[2]=sum of per-tile max V, out[3]=sum of V,
+// out[4]=sum over union nodes that are leaves, out[5]=sum of lanes active over all sweep steps
+// ---------------------------------------------------------------------------------------------
+extern "C" void orc_tile_union_stats(const uint32_t* packed, const float* constants, const void* light_v,
+                                     const float* positions, uint32_t W, uint32_t H, uint64_t* out) {
+    const OLight& lt = *(const OLight*)light_v;
+    uint64_t tiles = 0, sumU = 0, sumM = 0, sumV = 0, sumLeafU = 0;
+    const uint32_t tx = W / 8, ty = H / 8;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : tiles, sumU, sumM, sumV, sumLeafU)
+#endif
+    for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
+        uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
+        std::vector<u32> visited;
+        u32 maxV = 0;
+        for (u32 l = 0; l < 64; ++l) {
+            u32 x = bx * 8 + (l & 7), y = by * 8 + (l >> 3);
+            size_t pix = (size_t)y * W + x;
+            V3 rel = { positions[pix * 4 + 0], positions[pix * 4 + 1], positions[pix * 4 + 2] };
+            V3 o, d; float tmax;
+            genRay(constants, rel, lt, 0, &o, &tmax, &d);
+            V3 invdir = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+            u32 node = 0, v = 0;
+            while (node != kInvalid) {
+                const u32* a = packed + (size_t)node * 8; const u32* b = a + 4;
+                ++v; visited.push_back(node);
+                if (a[3] != kInvalid) {
+                    const u32* tt = packed + (size_t)a[3] * 4;
+                    V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+                    V3 v0 = { u2f(tt[0]), u2f(tt[1]), u2f(tt[2]) };
+                    if (rayTri(o, tmax, d, v0, e0, e1)) break;
+                } else {
+                    V3 pmin = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, pmax = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+                    if (rayBox(o, invdir, pmin, pmax)) { ++node; continue; }
+                }
+                node = b[3];
+            }
+            sumV += v; if (v > maxV) maxV = v;
+        }
+        std::sort(visited.begin(), visited.end());
+        visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
+        sumU += visited.size(); sumM += maxV; ++tiles;
+        for (u32 n : visited) if (packed[(size_t)n * 8 + 3] != kInvalid) ++sumLeafU;
+    }
+    out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = sumLeafU; out[5] = 0;
+}

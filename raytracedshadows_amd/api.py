@@ -20,7 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "librts.so")
+    # RTS_LIB lets an experiment load an alternative build of the SAME library (e.g. other compiler flags)
+    return os.environ.get("RTS_LIB") or os.path.join(_HERE, "librts.so")
 
 
 class RtsError(RuntimeError):

@@ -19,7 +19,7 @@ struct rts_ctx {
     uint32_t P = 0;
     bool bvhFinite = false;
     int variant = rts::V_STRAIGHT;
-    int swizzle = 1;
+    int swizzle = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // staging for the host-pointer entries
     void* d_in = nullptr; size_t inBytes = 0;

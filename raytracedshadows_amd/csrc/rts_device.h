@@ -9,6 +9,7 @@ enum Variant {
     V_STRAIGHT = 0,    // loop as the shader spells it
     V_WHILEWHILE = 1,  // inner-node descent loop + batched leaf test
     V_POSTPONE = 2,    // leaves parked in registers, tested wave-wide
+    V_PACKET = 3,      // wave walks the union of its rays' paths; nodes via scalar loads
     V_COUNT
 };
 
