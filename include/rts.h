@@ -151,8 +151,11 @@ int rts_stream_synchronize(rts_ctx* ctx, void* stream);
 int rts_timer_begin(rts_ctx* ctx, void* stream);
 int rts_timer_end(rts_ctx* ctx, void* stream);
 int rts_timer_elapsed_ms(rts_ctx* ctx, float* ms);
-/* Name of the kernel the last trace launched (for matching rocprofv3 rows), launches so far. */
+/* Name of the kernel the last trace launched (for matching rocprofv3 rows). */
 const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
+/* Diagnostics (tools/wave_stats.py): after rts_ctx_set_option(ctx, "wave_stats", n_waves) the packet
+ * kernels record {start clock, end clock, side-steps left, block xy} per wave; this copies them out. */
+int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
 
 #ifdef __cplusplus
 }

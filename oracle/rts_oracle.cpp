@@ -481,9 +481,16 @@ int orc_max_threads(void) {
 // ---------------------------------------------------------------------------------------------
 extern "C" void orc_tile_union_stats(const uint32_t* packed, const float* constants, const void* light_v,
                                      const float* positions, uint32_t W, uint32_t H, uint64_t* out) {
+    extern void orc_tile_union_stats_wh(const uint32_t*, const float*, const void*, const float*, uint32_t, uint32_t,
+                                        uint32_t, uint32_t, uint64_t*);
+    orc_tile_union_stats_wh(packed, constants, light_v, positions, W, H, 8, 8, out);
+}
+extern "C" void orc_tile_union_stats_wh(const uint32_t* packed, const float* constants, const void* light_v,
+                                        const float* positions, uint32_t W, uint32_t H, uint32_t TW, uint32_t TH,
+                                        uint64_t* out) {
     const OLight& lt = *(const OLight*)light_v;
     uint64_t tiles = 0, sumU = 0, sumM = 0, sumV = 0, sumLeafU = 0;
-    const uint32_t tx = W / 8, ty = H / 8;
+    const uint32_t tx = W / TW, ty = H / TH;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : tiles, sumU, sumM, sumV, sumLeafU)
 #endif
@@ -491,8 +498,8 @@ extern "C" void orc_tile_union_stats(const uint32_t* packed, const float* consta
         uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
         std::vector<u32> visited;
         u32 maxV = 0;
-        for (u32 l = 0; l < 64; ++l) {
-            u32 x = bx * 8 + (l & 7), y = by * 8 + (l >> 3);
+        for (u32 l = 0; l < TW * TH; ++l) {
+            u32 x = bx * TW + (l % TW), y = by * TH + (l / TW);
             size_t pix = (size_t)y * W + x;
             V3 rel = { positions[pix * 4 + 0], positions[pix * 4 + 1], positions[pix * 4 + 2] };
             V3 o, d; float tmax;

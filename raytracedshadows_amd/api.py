@@ -133,6 +133,7 @@ _sig("rts_timer_begin", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_timer_end", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_timer_elapsed_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
+_sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
      C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
 _sig("rtsh_obj_load", C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, _u32p, _f32p, _f32p)
@@ -297,6 +298,11 @@ class ShadowContext:
 
     def last_kernel_name(self):
         return _lib.rts_ctx_last_kernel_name(self._h).decode()
+
+    def read_wave_stats(self, waves):
+        out = np.zeros((waves, 4), dtype=np.uint64)
+        _check(_lib.rts_ctx_read_wave_stats(self._h, _ptr(out), waves), "rts_ctx_read_wave_stats")
+        return out
 
 
 # -- harness entry points -----------------------------------------------------------------------

@@ -18,13 +18,18 @@ struct rts_ctx {
     size_t bvhVec4 = 0;
     uint32_t P = 0;
     bool bvhFinite = false;
-    int variant = rts::V_STRAIGHT;
+    bool bvhOrdered = false;
+    int variant = rts::V_AUTO;
     int swizzle = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // staging for the host-pointer entries
     void* d_in = nullptr; size_t inBytes = 0;
     void* d_out = nullptr; size_t outBytes = 0;
     std::string lastKernel;
+    int packetBudget = 8;
+    int packetShare = 4;
+    int blockWaves = 1;
+    uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
 };
 
@@ -48,6 +53,9 @@ int fillParams(rts_ctx* ctx, TraceParams& p) {
     p.bvh = ctx->d_bvh;
     p.bvhBytes = (uint32_t)(ctx->bvhVec4 * 16);
     p.bvhFinite = ctx->bvhFinite ? 1u : 0u;
+    p.bvhOrdered = (ctx->bvhFinite && ctx->bvhOrdered) ? 1u : 0u;
+    p.packetBudget = (uint32_t)ctx->packetBudget;
+    p.packetShare = (uint32_t)ctx->packetShare;
     return RTS_OK;
 }
 
@@ -137,6 +145,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_waveStats) (void)hipFree(c->d_waveStats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -149,23 +158,42 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     int s = rts_bvh_validate(packed, count, &P);
     if (s != RTS_OK) return s;
     const uint64_t N = 2ull * P - 1;
-    bool finite = true;
+    bool finite = true, ordered = true;
     for (uint64_t i = 0; i < 2 * N + P && finite; ++i) {
         float f[3]; memcpy(f, &packed[i], 12);
         finite = std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2]);
     }
+    for (uint64_t i = 0; i < N && ordered; ++i) {
+        if (packed[2 * i].d != 0xFFFFFFFFu) continue;                 // leaves carry edges, not boxes
+        float lo[3], hi[3]; memcpy(lo, &packed[2 * i], 12); memcpy(hi, &packed[2 * i + 1], 12);
+        ordered = lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2];
+    }
+    if (count * 16 >= (1ull << 32)) return RTS_ERR_BAD_BVH;            // 32-bit byte offsets on the device
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
     RTS_HIP(hipMalloc(&c->d_bvh, count * 16));
     RTS_HIP(hipMemcpy(c->d_bvh, packed, count * 16, hipMemcpyHostToDevice));
-    c->bvhVec4 = count; c->P = P; c->bvhFinite = finite;
+    c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
     return RTS_OK;
 }
 
 int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!c || !key) return RTS_ERR_INVALID_ARG;
-    if (!strcmp(key, "kernel")) { if (value < 0 || value >= rts::V_COUNT) return RTS_ERR_INVALID_ARG; c->variant = value; return RTS_OK; }
+    if (!strcmp(key, "kernel")) { if (value < rts::V_AUTO || value >= rts::V_COUNT) return RTS_ERR_INVALID_ARG; c->variant = value; return RTS_OK; }
     if (!strcmp(key, "xcd_swizzle")) { c->swizzle = value ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "packet_budget")) { if (value < 1) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
+    if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
+    if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
+    if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
+        RTS_HIP(hipSetDevice(c->device));
+        if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
+        if (value > 0) {
+            c->waveStatsBytes = (size_t)value * 32;
+            RTS_HIP(hipMalloc((void**)&c->d_waveStats, c->waveStatsBytes));
+            RTS_HIP(hipMemset(c->d_waveStats, 0, c->waveStatsBytes));
+        }
+        return RTS_OK;
+    }
     return RTS_ERR_INVALID_ARG;
 }
 
@@ -173,8 +201,12 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return RTS_ERR_INVALID_ARG;
     if (!strcmp(key, "kernel")) { *value = c->variant; return RTS_OK; }
     if (!strcmp(key, "xcd_swizzle")) { *value = c->swizzle; return RTS_OK; }
+    if (!strcmp(key, "packet_budget")) { *value = c->packetBudget; return RTS_OK; }
+    if (!strcmp(key, "block_waves")) { *value = c->blockWaves; return RTS_OK; }
+    if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
 }
 
@@ -192,11 +224,20 @@ int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_l
     p.positions = (const float4*)d_positions;
     p.mask = d_mask;
     p.W = W; p.H = H; p.rowBegin = row_begin; p.rowEnd = row_end;
-    p.blocksX = (W + 15) / 16;
-    p.blocksY = (row_end - row_begin + 15) / 16;
+    // V_AUTO: a packet's steps are a dependent chain, so it needs several waves per SIMD to overlap them;
+    // a launch with fewer than ~4 waves per SIMD is faster lane-per-ray.  (Bigger packets, V_PACKET2/4, were
+    // measured slower or equal on every BASELINE config and are kept as selectable variants only.)
+    int variant = c->variant;
+    const uint64_t pixels = (uint64_t)W * (row_end - row_begin);
+    if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_STRAIGHT;
+    uint32_t bw, bh;
+    rts::tileShape(variant, c->blockWaves, &bw, &bh);
+    p.blocksX = (W + bw - 1) / bw;
+    p.blocksY = (row_end - row_begin + bh - 1) / bh;
     p.nBlocks = p.blocksX * p.blocksY;
     p.swizzle = c->swizzle ? 1u : 0u;
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
+    if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) p.waveStats = c->d_waveStats;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;
@@ -208,9 +249,9 @@ int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_l
         p.nsamples = 1;
         for (int i = 0; i < 3; ++i) p.light[i] = k->lightDirection[i];
     }
-    c->lastKernel = rts::kernelName(c->variant, true);
+    c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
-    return hipStatus(rts::launchShadowMask(c->variant, p, (hipStream_t)stream));
+    return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream));
 }
 
 int rts_trace_shadow_mask(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* positions,
@@ -241,9 +282,11 @@ int rts_trace_rays_device(rts_ctx* c, const rts_ray* d_rays, size_t n, uint8_t* 
     if (n == 0) return RTS_OK;
     RTS_HIP(hipSetDevice(c->device));
     p.rays = d_rays; p.out = d_out; p.nrays = n;
-    c->lastKernel = rts::kernelName(c->variant, false);
+    // generic rays carry no coherence promise: lane-per-ray unless the caller asks for a variant
+    const int variant = c->variant == rts::V_AUTO ? rts::V_STRAIGHT : c->variant;
+    c->lastKernel = rts::kernelName(variant, false);
     ++c->launches;
-    return hipStatus(rts::launchTraceRays(c->variant, p, (hipStream_t)stream));
+    return hipStatus(rts::launchTraceRays(variant, p, (hipStream_t)stream));
 }
 
 int rts_trace_rays(rts_ctx* c, const rts_ray* rays, size_t n, uint8_t* out) {
@@ -311,5 +354,12 @@ int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
     return RTS_OK;
 }
 const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel.c_str() : ""; }
+
+int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {
+    if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMemcpy(out, c->d_waveStats, waves * 32, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
 
 } // extern "C"

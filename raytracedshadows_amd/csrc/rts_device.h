@@ -9,8 +9,11 @@ enum Variant {
     V_STRAIGHT = 0,    // loop as the shader spells it
     V_WHILEWHILE = 1,  // inner-node descent loop + batched leaf test
     V_POSTPONE = 2,    // leaves parked in registers, tested wave-wide
-    V_PACKET = 3,      // wave walks the union of its rays' paths; nodes via scalar loads
-    V_COUNT
+    V_PACKET = 3,      // wave (8x8 px) walks the union of its rays' paths; nodes via scalar loads
+    V_PACKET2 = 4,     // same, 2 rays per lane (16x8 px per wave)
+    V_PACKET4 = 5,     // same, 4 rays per lane (16x16 px per wave)
+    V_COUNT,
+    V_AUTO = -1        // packet for big launches, straight for small ones
 };
 
 // Kernel argument block (passed by value; lives in the kernarg segment, read with scalar loads).
@@ -18,6 +21,7 @@ struct TraceParams {
     const void* bvh;          // packed vec4 stream, SURVEY.md Appendix A (device)
     uint32_t bvhBytes;
     uint32_t bvhFinite;       // every float of the stream is finite -> FAST slab test is legal
+    uint32_t bvhOrdered;      // ... and every inner node has bboxMin <= bboxMax -> ordered slab test is legal
     // mask dispatch
     const float4* positions;  // W x H RGBA32F, camera-relative (device)
     uint8_t* mask;            // W x H bytes (device)
@@ -30,11 +34,15 @@ struct TraceParams {
     const void* rays;         // rts_ray[n] (device)
     uint8_t* out;
     uint64_t nrays;
+    uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
+    uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
+    uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
     float offsets[64][4];
 };
 
 const char* kernelName(int variant, bool mask);
-hipError_t launchShadowMask(int variant, const TraceParams& p, hipStream_t stream);
+void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH);   // pixels covered by one block
+hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream);
 hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream);
 
 } // namespace rts

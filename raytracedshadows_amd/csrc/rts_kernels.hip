@@ -245,8 +245,8 @@ typedef const __attribute__((address_space(4))) u32x8* ConstNodePtr;
 typedef const __attribute__((address_space(4))) u32x4* ConstVec4Ptr;
 
 // A coherent 8x8 tile needs 40-70 packet steps on the BASELINE scenes (union of its rays' paths); 64
-// unrelated rays would need thousands.  After this many steps the packet dissolves and each lane goes on alone.
-static constexpr int32_t PACKET_MAX_STEPS = 192;
+// unrelated rays would need thousands.  After TraceParams::packetBudget side-steps the packet dissolves and
+// each ray goes on alone.
 
 __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
     // smallest value over all 64 lanes (inactive-by-value lanes carry END = 0xFFFFFFFF)
@@ -262,152 +262,138 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
     return m;
 }
 
-// Packet state: `members` (wave-uniform 64-bit mask, SGPR pair) = lanes walking with the packet, i.e.
-// standing on `cur`; `wait` (per lane) = the node a lane that left the packet waits on (END = nothing
-// to wait for: finished or never started).  A lane leaves when its own test fails (box miss / triangle
-// miss) and always waits on next(cur); the packet picks it up again when `cur` gets there.
+// Packet state: `members[k]` (wave-uniform 64-bit masks, SGPR pairs) = lanes whose ray of set k walks
+// with the packet, i.e. stands on `cur`; `wait[k]` (per lane) = the node a ray that left the packet
+// waits on (END = nothing to wait for: finished or never started).  A ray leaves when its own test
+// fails (box miss / triangle miss) and always waits on next(cur); the packet picks it up again when
+// `cur` gets there.  A lane carries K rays (K = 1, 2, 4: the wave is an 8x8, 16x8, 16x16 pixel tile):
+// the union of the paths grows slowly with the tile (41 / 48 / 53 nodes on the headline frame), so
+// more rays per lane means fewer dependent scalar loads per ray at the same VALU work.
+//
+// The descent over inner nodes is hand-written gfx950 assembly (rts_packet_asm.inc, generated by
+// tools/gen_packet_asm.py): per step one s_load_dwordx8, K slab tests, ~6+5K scalar ops.
+// Slab test, "ordered" form: for a lane with 1/d.x > 0,  f = (hi.x-o.x)*inv.x >= n = (lo.x-o.x)*inv.x
+// because lo.x <= hi.x and IEEE subtraction, multiplication by a positive number and rounding are all
+// monotone; so the shader's tmax.x = max(f,n) IS f and tmin.x = min(f,n) IS n (equal values are
+// interchangeable), and the other way round for 1/d.x < 0.  When every ray of the wave has the same
+// sign pattern the choice of plane is a compile-time operand swap (8 instantiations) and the six
+// per-axis min/max disappear: t1 = min3(far), t0 = max(max3(near), 0), hit = t1 >= t0 -- the same
+// values the FAST/EXACT forms compare.  Preconditions: no NaN can occur (FAST rule), every inner node
+// has bboxMin <= bboxMax (checked at upload), uniform sign pattern; otherwise the generic FAST form
+// (v_min/v_max per axis) runs, and waves with an unsafe ray go lane-per-ray with the EXACT form.
+#include "rts_packet_asm.inc"
 
-// Hot loop, hand-written for gfx950: walk inner nodes from `cur` until the packet stands on a leaf
-// (returns 1, node in n[0..7]), or runs out of nodes (cur == END) or of steps (both return 0).
-// Per step: 1 scalar load (32 B), 27 VALU, 9 SALU.  The slab test is the FAST form (v_min/v_max;
-// legal only when no NaN can occur, see the top of this file), operation for operation what the
-// compiler emits for boxHit<true>.  Fixed scratch SGPRs s[40:52] keep the node tuple addressable.
-// Hazards: the only VALU-written SGPRs (vcc from v_cmp_ge, `mem` from v_cmp_eq) are read by SALU
-// instructions, which the hardware interlocks; v_cndmask reads an SALU-written mask.
-__device__ __forceinline__ uint32_t packetDescendFast(const void* base, const Ray& r, uint32_t& cur, uint64_t& members,
-                                                      uint32_t& wait, int32_t& budget, uint32_t (&n)[8]) {
-    uint32_t leaf;
-    float t0, t1, t2, t3, t4, t5, t6;
-    asm volatile(
-        "2:\n\t"
-        "s_lshl_b32 s52, %[cur], 5\n\t"
-        "s_load_dwordx8 s[40:47], %[base], s52\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_cmp_lg_u32 s43, -1\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "v_sub_f32 %[t0], s44, %[ox]\n\t"
-        "v_sub_f32 %[t1], s45, %[oy]\n\t"
-        "v_sub_f32 %[t2], s46, %[oz]\n\t"
-        "v_sub_f32 %[t3], s40, %[ox]\n\t"
-        "v_sub_f32 %[t4], s41, %[oy]\n\t"
-        "v_sub_f32 %[t5], s42, %[oz]\n\t"
-        "v_mul_f32 %[t0], %[t0], %[ix]\n\t"
-        "v_mul_f32 %[t1], %[t1], %[iy]\n\t"
-        "v_mul_f32 %[t2], %[t2], %[iz]\n\t"
-        "v_mul_f32 %[t3], %[t3], %[ix]\n\t"
-        "v_mul_f32 %[t4], %[t4], %[iy]\n\t"
-        "v_mul_f32 %[t5], %[t5], %[iz]\n\t"
-        "v_max_f32 %[t6], %[t0], %[t3]\n\t"
-        "v_min_f32 %[t0], %[t0], %[t3]\n\t"
-        "v_max_f32 %[t3], %[t1], %[t4]\n\t"
-        "v_min_f32 %[t1], %[t1], %[t4]\n\t"
-        "v_max_f32 %[t4], %[t2], %[t5]\n\t"
-        "v_min_f32 %[t2], %[t2], %[t5]\n\t"
-        "v_min3_f32 %[t6], %[t6], %[t3], %[t4]\n\t"
-        "v_max_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_max3_f32 %[t0], %[t0], %[t2], 0\n\t"
-        "v_cmp_ge_f32 vcc, %[t6], %[t0]\n\t"
-        "v_mov_b32 %[t1], s47\n\t"
-        "s_andn2_b64 s[50:51], %[mem], vcc\n\t"
-        "s_and_b64 s[48:49], %[mem], vcc\n\t"
-        "v_cndmask_b32 %[wait], %[wait], %[t1], s[50:51]\n\t"
-        "s_cbranch_scc0 3f\n\t"
-        "s_mov_b64 %[mem], s[48:49]\n\t"
-        "s_add_u32 %[cur], %[cur], 1\n\t"
-        "s_sub_u32 %[budget], %[budget], 1\n\t"
-        "s_cbranch_scc0 2b\n\t"
-        "s_branch 8f\n\t"
-        "3:\n\t"
-        "s_mov_b32 %[cur], s47\n\t"
-        "s_cmp_eq_u32 s47, -1\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "v_cmp_eq_u32 %[mem], s47, %[wait]\n\t"
-        "s_sub_u32 %[budget], %[budget], 1\n\t"
-        "s_cbranch_scc0 2b\n\t"
-        "8:\n\t"
-        "s_mov_b32 %[leaf], 0\n\t"
-        "s_branch 7f\n\t"
-        "9:\n\t"
-        "s_mov_b32 %[leaf], 1\n\t"
-        "7:\n\t"
-        "s_mov_b32 %[n0], s40\n\t"
-        "s_mov_b32 %[n1], s41\n\t"
-        "s_mov_b32 %[n2], s42\n\t"
-        "s_mov_b32 %[n3], s43\n\t"
-        "s_mov_b32 %[n4], s44\n\t"
-        "s_mov_b32 %[n5], s45\n\t"
-        "s_mov_b32 %[n6], s46\n\t"
-        "s_mov_b32 %[n7], s47\n\t"
-        : [cur] "+s"(cur), [mem] "+s"(members), [wait] "+v"(wait), [budget] "+s"(budget), [leaf] "=&s"(leaf),
-          [n0] "=&s"(n[0]), [n1] "=&s"(n[1]), [n2] "=&s"(n[2]), [n3] "=&s"(n[3]),
-          [n4] "=&s"(n[4]), [n5] "=&s"(n[5]), [n6] "=&s"(n[6]), [n7] "=&s"(n[7]),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6)
-        : [base] "s"(base), [ox] "v"(r.o.x), [oy] "v"(r.o.y), [oz] "v"(r.o.z),
-          [ix] "v"(r.inv.x), [iy] "v"(r.inv.y), [iz] "v"(r.inv.z)
-        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "vcc", "scc");
-    return leaf;
-}
-
-template <bool FAST>
-__device__ __forceinline__ bool traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live) {
+template <int K>
+__device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
+                                               const bool (&live)[K], bool (&result)[K], int32_t* sideStepsLeft = nullptr) {
     const ConstNodePtr nodes = (ConstNodePtr)(uintptr_t)p.bvh;
     const ConstVec4Ptr vec4s = (ConstVec4Ptr)(uintptr_t)p.bvh;
-    uint64_t members = __builtin_amdgcn_ballot_w64(live);
-    if (members == 0) return false;
-    uint64_t occluded = 0;               // wave-uniform mask of lanes whose ray hit a triangle
-    uint32_t wait = END;
-    uint32_t cur = 0;
-    int32_t budget = PACKET_MAX_STEPS;
-    do {                                             // single-exit loop: keeps the scalar control flow lean
-        uint32_t n[8];
-        bool leaf;
-        if (FAST) {
-            leaf = packetDescendFast(p.bvh, r, cur, members, wait, budget, n) != 0;
-        } else {
-            // EXACT form (NaN-propagating compare-selects), compiled: one node per trip
-            const u32x8 v = nodes[cur];              // s_load_dwordx8: {a.xyz, a.w | b.xyz, b.w}
-            n[0] = v.s0; n[1] = v.s1; n[2] = v.s2; n[3] = v.s3; n[4] = v.s4; n[5] = v.s5; n[6] = v.s6; n[7] = v.s7;
-            leaf = n[3] != END;
-            if (!leaf) {
-                const bool h = boxHit<false>(r, __uint_as_float(n[0]), __uint_as_float(n[1]), __uint_as_float(n[2]),
-                                             __uint_as_float(n[4]), __uint_as_float(n[5]), __uint_as_float(n[6]));
-                const uint64_t in = __builtin_amdgcn_ballot_w64(h) & members;
-                wait = __builtin_amdgcn_inverse_ballot_w64(members & ~in) ? n[7] : wait;
-                if (in != 0) { members = in; cur = cur + 1; }
-                else { cur = n[7]; members = __builtin_amdgcn_ballot_w64(wait == n[7]); }
-                --budget;
-            }
-        }
-        if (leaf) {
-            const uint32_t next = n[7];
-            const u32x4 t = vec4s[n[3]];
-            const F3 e0{ __uint_as_float(n[0]), __uint_as_float(n[1]), __uint_as_float(n[2]) };
-            const F3 e1{ __uint_as_float(n[4]), __uint_as_float(n[5]), __uint_as_float(n[6]) };
-            const uint64_t hit = __builtin_amdgcn_ballot_w64(triHit(r, xyz(t), e0, e1)) & members;
-            occluded |= hit;
-            wait = __builtin_amdgcn_inverse_ballot_w64(members & ~hit) ? next : wait;
-            wait = __builtin_amdgcn_inverse_ballot_w64(hit) ? END : wait;
-            cur = next;
-            members = __builtin_amdgcn_ballot_w64(wait == cur);
-            if (members == 0) {                      // everyone here got occluded: jump to the lowest waiting index
-                cur = waveMinU32(wait);
-                members = __builtin_amdgcn_ballot_w64(wait == cur);
-            }
-        }
-    } while (cur != END && budget >= 0);
-    bool result = __builtin_amdgcn_inverse_ballot_w64(occluded);
-    if (cur != END) {
-        // step budget exhausted: every unfinished lane continues alone from the node it stands or waits on
-        const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members) ? cur : wait;
-        const bool h = traverseStraight<FAST>(bvh, r, mine != END, mine);
-        result = result || h;
+    uint64_t members[K], occluded[K];
+    uint32_t wait[K];
+    uint64_t any = 0, unsafe = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        members[k] = __builtin_amdgcn_ballot_w64(live[k]);
+        any |= members[k];
+        unsafe |= __builtin_amdgcn_ballot_w64(live[k] && !raySafe(r[k]));
+        occluded[k] = 0;
+        wait[k] = END;
+        result[k] = false;
     }
-    return result;
+    if (any == 0) return;
+    if (!p.bvhFinite || unsafe != 0) {       // a NaN could occur somewhere in this wave: EXACT form, lane per ray
+#pragma unroll
+        for (int k = 0; k < K; ++k) result[k] = traverseStraight<false>(bvh, r[k], live[k]);
+        return;
+    }
+    // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test
+    uint32_t form = 8;
+    if (p.bvhOrdered) {
+        bool uniform = true;
+        uint32_t octant = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            uint64_t neg = 0, pos = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float v = a == 0 ? r[k].inv.x : (a == 1 ? r[k].inv.y : r[k].inv.z);
+                const uint64_t n = __builtin_amdgcn_ballot_w64(v < 0.0f) & members[k];
+                neg |= n;
+                pos |= members[k] & ~n;
+            }
+            uniform = uniform && (neg == 0 || pos == 0);
+            octant |= neg ? (1u << a) : 0u;
+        }
+        if (uniform) form = octant;
+    }
+    form = (uint32_t)__builtin_amdgcn_readfirstlane((int)form);
+    // Dissolve rule (evaluated inside the asm loop).  A packet step serves the rays standing on `cur`; a
+    // lane-per-ray step serves every unfinished ray of the wave but costs about twice as much.  Every
+    // p.packetBudget side-steps the rays picked up per side-step are compared with the rays still alive:
+    // below p.packetShare/16 of them it is cheaper to let every ray continue alone (atrium: 92 % of the rays
+    // die early and the rest scatter between the columns).
+    uint32_t cur = 0;
+    const uint32_t window = p.packetBudget - 1u;
+    const uint32_t thr = p.packetBudget * p.packetShare;
+    int32_t budget = (int32_t)window;
+    uint32_t acc = 0;
+    bool leaf;
+    do {
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        budget = __builtin_amdgcn_readfirstlane(budget);
+        acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            members[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(members[k] >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)members[k]);
+        leaf = packetDescend(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;
+        if (leaf) {
+            // the packet stands on a leaf: one triangle, tested by the rays that are here
+            const u32x8 n = nodes[cur];
+            const u32x4 t = vec4s[n.s3];
+            const uint32_t next = n.s7;
+            const F3 e0{ __uint_as_float(n.s0), __uint_as_float(n.s1), __uint_as_float(n.s2) };
+            const F3 e1{ __uint_as_float(n.s4), __uint_as_float(n.s5), __uint_as_float(n.s6) };
+            uint64_t here = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (members[k] != 0) {
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(triHit(r[k], xyz(t), e0, e1)) & members[k];
+                    occluded[k] |= hit;
+                    wait[k] = __builtin_amdgcn_inverse_ballot_w64(members[k] & ~hit) ? next : wait[k];
+                    wait[k] = __builtin_amdgcn_inverse_ballot_w64(hit) ? END : wait[k];
+                }
+                members[k] = __builtin_amdgcn_ballot_w64(wait[k] == next);
+                here |= members[k];
+            }
+            cur = next;
+            if (here == 0) {                 // every ray that stood here got occluded: go to the lowest waiting node
+                uint32_t lowest = END;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { const uint32_t m = waveMinU32(wait[k]); lowest = m < lowest ? m : lowest; }
+                cur = lowest;
+#pragma unroll
+                for (int k = 0; k < K; ++k) members[k] = __builtin_amdgcn_ballot_w64(wait[k] == cur);
+            }
+        }
+    } while (leaf && cur != END);
+    const bool dissolve = cur != END;
+#pragma unroll
+    for (int k = 0; k < K; ++k) result[k] = __builtin_amdgcn_inverse_ballot_w64(occluded[k]);
+    if (sideStepsLeft) *sideStepsLeft = dissolve ? -1 : 0;
+    if (cur != END) {
+        // dissolved (not coherent enough for a packet): every unfinished ray continues alone
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
+            const bool h = traverseStraight<true>(bvh, r[k], mine != END, mine);
+            result[k] = result[k] || h;
+        }
+    }
 }
 
 template <int VARIANT, bool FAST>
 __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live) {
-    if (VARIANT == V_PACKET) return traversePacket<FAST>(p, bvh, r, live);
     if (VARIANT == V_WHILEWHILE) return traverseWhileWhile<FAST>(bvh, r, live);
     if (VARIANT == V_POSTPONE) return traversePostpone<FAST>(bvh, r, live);
     return traverseStraight<FAST>(bvh, r, live);
@@ -472,6 +458,60 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
     if (live) __builtin_nontemporal_store((uint8_t)lit, &p.mask[pix]);   // comp:150
 }
 
+// Packet kernels: a wave is a (8 or 16) x (8 or 16) pixel tile, a lane carries K = 1, 2 or 4 rays (the
+// 8x8 sub-tiles of its wave tile), a 256-thread block is 2x2 wave tiles.
+// WPB = waves per block: 4 (block = 2x2 wave tiles) or 1 (block = one wave tile, so that a finished wave
+// frees its slot without waiting for three siblings).
+template <int K, int WPB>
+__global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p) {
+    constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
+    uint32_t bx, by;
+    if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);
+    const uint32_t y0 = p.rowBegin + (WPB == 4 ? by * (2u * TH) + (wave >> 1) * TH : by * TH) + (lane >> 3);
+    bool live[K];
+    size_t pix[K];
+    F3 rel[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t x = x0 + (k & 1) * 8u, y = y0 + (k >> 1) * 8u;
+        live[k] = (x < p.W) && (y < p.rowEnd);
+        pix[k] = (size_t)y * p.W + x;
+        rel[k] = F3{ 0.f, 0.f, 0.f };
+        if (live[k]) {
+            f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix[k]);   // comp:135
+            rel[k] = F3{ t.x, t.y, t.z };
+        }
+    }
+    const NodeStream bvh = openStream(p);
+    const uint32_t ns = p.nsamples > 1 ? p.nsamples : 1u;
+    const uint64_t tStart = p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
+    int32_t left = 0;
+    uint32_t lit[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lit[k] = 0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        Ray r[K];
+        bool occluded[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
+        traversePacket<K>(p, bvh, r, live, occluded, &left);
+#pragma unroll
+        for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);       // comp:150
+    if (p.waveStats && lane == 0) {              // diagnostics: never read by any kernel, never part of an output
+        uint64_t* o = p.waveStats + ((size_t)blockIdx.x * WPB + wave) * 4;
+        o[0] = tStart;
+        o[1] = __builtin_amdgcn_s_memtime();
+        o[2] = (uint64_t)(uint32_t)left;
+        o[3] = ((uint64_t)bx << 32) | by;
+    }
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -485,12 +525,20 @@ __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     }
     r.inv = F3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };
     const NodeStream bvh = openStream(p);
-    bool unsafe = live && !raySafe(r);
     bool occluded;
-    if (p.bvhFinite && __builtin_amdgcn_ballot_w64(unsafe) == 0)
-        occluded = traverse<VARIANT, true>(p, bvh, r, live);
-    else
-        occluded = traverse<VARIANT, false>(p, bvh, r, live);
+    if (VARIANT >= V_PACKET) {                   // 64 consecutive rays as one packet (falls apart if incoherent)
+        const Ray rr[1] = { r };
+        const bool ll[1] = { live };
+        bool oo[1];
+        traversePacket<1>(p, bvh, rr, ll, oo);
+        occluded = oo[0];
+    } else {
+        bool unsafe = live && !raySafe(r);
+        if (p.bvhFinite && __builtin_amdgcn_ballot_w64(unsafe) == 0)
+            occluded = traverse<VARIANT, true>(p, bvh, r, live);
+        else
+            occluded = traverse<VARIANT, false>(p, bvh, r, live);
+    }
     if (live) p.out[i] = occluded ? 0 : 1;
 }
 
@@ -502,18 +550,38 @@ const char* kernelName(int variant, bool mask) {
     case V_STRAIGHT: return mask ? "shadowMaskKernel<0>" : "traceRaysKernel<0>";
     case V_WHILEWHILE: return mask ? "shadowMaskKernel<1>" : "traceRaysKernel<1>";
     case V_POSTPONE: return mask ? "shadowMaskKernel<2>" : "traceRaysKernel<2>";
-    case V_PACKET: return mask ? "shadowMaskKernel<3>" : "traceRaysKernel<3>";
+    case V_PACKET: return mask ? "shadowMaskPacketKernel<1>" : "traceRaysKernel<3>";
+    case V_PACKET2: return mask ? "shadowMaskPacketKernel<2>" : "traceRaysKernel<3>";
+    case V_PACKET4: return mask ? "shadowMaskPacketKernel<4>" : "traceRaysKernel<3>";
     }
     return "?";
 }
 
-hipError_t launchShadowMask(int variant, const TraceParams& p, hipStream_t stream) {
+void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH) {
+    const uint32_t f = (variant >= V_PACKET && wavesPerBlock == 1) ? 1u : 2u;   // block = f x f wave tiles
+    *blockW = f * ((variant == V_PACKET2 || variant == V_PACKET4) ? 16u : 8u);
+    *blockH = f * (variant == V_PACKET4 ? 16u : 8u);
+}
+
+hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream) {
     dim3 grid(p.gridBlocks), block(256);
+    if (variant >= V_PACKET && wavesPerBlock == 1) {
+        dim3 b1(64);
+        switch (variant) {
+        case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, 0, stream, p); break;
+        case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1>), grid, b1, 0, stream, p); break;
+        case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1>), grid, b1, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (variant) {
     case V_STRAIGHT: hipLaunchKernelGGL(shadowMaskKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(shadowMaskKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(shadowMaskKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
-    case V_PACKET: hipLaunchKernelGGL(shadowMaskKernel<V_PACKET>, grid, block, 0, stream, p); break;
+    case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4>), grid, block, 0, stream, p); break;
+    case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4>), grid, block, 0, stream, p); break;
+    case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -525,7 +593,8 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
     case V_STRAIGHT: hipLaunchKernelGGL(traceRaysKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(traceRaysKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(traceRaysKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
-    case V_PACKET: hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
+    case V_PACKET: case V_PACKET2: case V_PACKET4:
+        hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

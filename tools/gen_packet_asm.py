@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Generates raytracedshadows_amd/csrc/rts_packet_asm.inc: the hand-written gfx950 descent loop of the
+packet kernels, instantiated for K = 1, 2, 4 ray sets per lane and 9 slab-test forms (8 sign octants
+of the "ordered" test + the generic min/max test).  The .inc file is committed; re-run this script
+after editing the loop:
+
+    python tools/gen_packet_asm.py
+
+Register plan inside the asm (fixed scratch SGPRs, declared as clobbers):
+    s[40:47]  node: s40-42 bboxMin, s43 leaf tag, s44-46 bboxMax, s47 miss link
+    s[48:49]  saved EXEC          s[50:51]  leavers of the set being processed
+    s52       byte offset of the node (cur * 32)
+    s[54:61]  slab-test results of ray sets 0..3 (VALU-written, SALU-read: interlocked by hardware)
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "raytracedshadows_amd", "csrc", "rts_packet_asm.inc")
+
+LO = ["s40", "s41", "s42"]
+HI = ["s44", "s45", "s46"]
+AX = "xyz"
+
+
+def test_ordered(k, octant):
+    """16 VALU: far/near planes picked by the (wave-uniform) sign of 1/d per axis."""
+    far = [LO[a] if (octant >> a) & 1 else HI[a] for a in range(3)]
+    near = [HI[a] if (octant >> a) & 1 else LO[a] for a in range(3)]
+    L = []
+    for i, a in enumerate(AX):
+        L.append(f"v_sub_f32 %[t{i}], {far[i]}, %[o{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_sub_f32 %[t{3 + i}], {near[i]}, %[o{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_mul_f32 %[t{i}], %[t{i}], %[i{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_mul_f32 %[t{3 + i}], %[t{3 + i}], %[i{a}{k}]")
+    L += ["v_min3_f32 %[t0], %[t0], %[t1], %[t2]",
+          "v_max_f32 %[t3], %[t3], %[t4]",
+          "v_max3_f32 %[t3], %[t3], %[t5], 0",
+          f"v_cmp_ge_f32 s[{54 + 2 * k}:{55 + 2 * k}], %[t0], %[t3]"]
+    return L
+
+
+def test_generic(k):
+    """22 VALU: the FAST form of boxHit (v_min/v_max per axis), no assumption on signs or box order."""
+    L = []
+    for i, a in enumerate(AX):
+        L.append(f"v_sub_f32 %[t{i}], {HI[i]}, %[o{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_sub_f32 %[t{3 + i}], {LO[i]}, %[o{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_mul_f32 %[t{i}], %[t{i}], %[i{a}{k}]")
+    for i, a in enumerate(AX):
+        L.append(f"v_mul_f32 %[t{3 + i}], %[t{3 + i}], %[i{a}{k}]")
+    L += ["v_max_f32 %[t6], %[t0], %[t3]", "v_min_f32 %[t0], %[t0], %[t3]",
+          "v_max_f32 %[t3], %[t1], %[t4]", "v_min_f32 %[t1], %[t1], %[t4]",
+          "v_max_f32 %[t4], %[t2], %[t5]", "v_min_f32 %[t2], %[t2], %[t5]",
+          "v_min3_f32 %[t6], %[t6], %[t3], %[t4]",
+          "v_max_f32 %[t0], %[t0], %[t1]",
+          "v_max3_f32 %[t0], %[t0], %[t2], 0",
+          f"v_cmp_ge_f32 s[{54 + 2 * k}:{55 + 2 * k}], %[t6], %[t0]"]
+    return L
+
+
+def loop(K, form):
+    L = ["s_lshl_b32 s52, %[cur], 5",
+         "s_branch 2f",
+         "5:",
+         "s_add_u32 s52, s52, 32",                      # down-step: the left child is the next node in memory
+         "2:",
+         "s_load_dwordx8 s[40:47], %[base], s52",
+         "s_waitcnt lgkmcnt(0)",
+         "s_cmp_lg_u32 s43, -1",
+         "s_cbranch_scc1 9f"]                            # leaf: leave with cur = this node
+    for k in range(K):
+        L += test_generic(k) if form == 8 else test_ordered(k, form)
+    for k in range(K):
+        r = f"s[{54 + 2 * k}:{55 + 2 * k}]"
+        L += [f"s_andn2_b64 s[50:51], %[m{k}], {r}",   # members whose own test failed: they leave the packet ...
+              f"s_cbranch_scc0 1{k}f",
+              "s_mov_b64 s[48:49], exec",
+              "s_mov_b64 exec, s[50:51]",
+              f"v_mov_b32 %[w{k}], s47",                # ... and wait on the miss link
+              "s_mov_b64 exec, s[48:49]",
+              f"1{k}:",
+              f"s_and_b64 %[m{k}], %[m{k}], {r}"]      # the rest goes down
+    if K == 2:
+        L.append("s_or_b64 s[50:51], %[m0], %[m1]")
+    elif K == 4:
+        L += ["s_or_b64 s[50:51], %[m0], %[m1]", "s_or_b64 s[48:49], %[m2], %[m3]",
+              "s_or_b64 s[50:51], s[50:51], s[48:49]"]
+    L += ["s_cbranch_scc1 5b",                          # (K == 1: SCC still comes from the s_and above)
+          "s_lshl_b32 s52, s47, 5",                     # side-step: nobody entered the subtree
+          "s_cmp_eq_u32 s47, -1",
+          "s_cbranch_scc1 6f"]
+    for k in range(K):
+        L.append(f"v_cmp_eq_u32 %[m{k}], s47, %[w{k}]")  # whoever waits on that node is the packet now
+    for k in range(K):                                  # coherence statistics: rays picked up by this side-step
+        L += [f"s_bcnt1_i32_b64 s50, %[m{k}]", "s_add_u32 %[acc], %[acc], s50"]
+    L += ["s_sub_u32 %[budget], %[budget], 1",
+          "s_cbranch_scc0 2b"]
+    # a window of side-steps is over: rays picked up per side-step against rays alive (dissolve rule)
+    for k in range(K):
+        L += [f"v_cmp_ne_u32 s[48:49], -1, %[w{k}]",     # rays of set k that wait somewhere ...
+              f"s_or_b64 s[48:49], s[48:49], %[m{k}]",   # ... or walk with the packet
+              "s_bcnt1_i32_b64 s50, s[48:49]",
+              "s_add_u32 s51, s51, s50" if k else "s_mov_b32 s51, s50"]
+    L += ["s_mul_i32 s51, s51, %[thr]",                  # alive * window * share
+          "s_lshl_b32 s50, %[acc], 4",                    # picked up * 16
+          "s_mov_b32 %[acc], 0",
+          "s_mov_b32 %[budget], %[window]",
+          "s_cmp_lt_u32 s50, s51",
+          "s_cbranch_scc0 2b",                            # coherent enough: go on
+          "8:",                                           # dissolve: continue lane-per-ray at s52
+          "s_mov_b32 %[leaf], 0",
+          "s_lshr_b32 %[cur], s52, 5",
+          "s_branch 7f",
+          "6:",                                           # miss link END: finished
+          "s_mov_b32 %[leaf], 0",
+          "s_mov_b32 %[cur], -1",
+          "s_branch 7f",
+          "9:",
+          "s_mov_b32 %[leaf], 1",
+          "s_lshr_b32 %[cur], s52, 5",
+          "7:"]
+    return L
+
+
+def emit_asm(K, form, ind):
+    lines = loop(K, form)
+    body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
+    outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
+    outs += [f'[m{k}] "+s"(members[{k}])' for k in range(K)]
+    outs += [f'[w{k}] "+v"(wait[{k}])' for k in range(K)]
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(7)]
+    ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
+    for k in range(K):
+        ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
+    clob = [f'"s{i}"' for i in list(range(40, 53)) + list(range(54, 54 + 2 * K))] + ['"vcc"', '"scc"']
+    return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
+            f"{ind}    : {', '.join(clob)});\n")
+
+
+def main():
+    o = ["// GENERATED by tools/gen_packet_asm.py -- do not edit by hand.",
+         "// Descent loop of the packet kernels (see rts_kernels.hip, 'V_PACKET').  Walks inner nodes from `cur`",
+         "// until the packet stands on a leaf (returns 1, cur = that leaf), runs out of nodes (returns 0, cur = END)",
+         "// or decides to dissolve (returns 0, cur = node to continue at).  Dissolve rule: every `window`+1 side-steps",
+         "// the rays picked up at those side-steps (`acc`) are compared with the rays alive: acc*16 < alive*thr with",
+         "// thr = (window+1)*share dissolves the packet.",
+         "// form 0..7: ordered slab test for the sign octant (bit a set <=> 1/d component a negative in every lane);",
+         "// form 8: generic FAST slab test.", ""]
+    for K in (1, 2, 4):
+        o.append(f"__device__ __forceinline__ uint32_t packetDescend(uint32_t form, const void* base, const Ray (&r)[{K}],")
+        o.append(f"                                                uint32_t& cur, uint64_t (&members)[{K}], uint32_t (&wait)[{K}],")
+        o.append("                                                int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
+        o.append("    uint32_t leaf;")
+        o.append("    float t0, t1, t2, t3, t4, t5, t6;")
+        o.append("    switch (form) {")
+        for form in range(9):
+            o.append(f"    case {form}:" if form < 8 else "    default:")
+            o.append(emit_asm(K, form, "        ").rstrip("\n"))
+            o.append("        break;")
+        o.append("    }")
+        o.append("    return leaf;")
+        o.append("}")
+        o.append("")
+    open(OUT, "w").write("\n".join(o))
+    print("wrote", OUT, sum(1 for _ in open(OUT)), "lines")
+
+
+if __name__ == "__main__":
+    main()
