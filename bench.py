@@ -39,7 +39,7 @@ def log(*a):
 def load_traffic(kernel_name, workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/*traffic*.json), or None."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "*traffic*.json"), recursive=True)):
         try:
             rec = json.load(open(path))
         except Exception:
@@ -190,16 +190,18 @@ def main():
             oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, wl.positions, W, H, threads=threads, out=scratch)
             reps += 1
         t_all = (time.perf_counter() - t0) / reps
-        rows1 = max(8, H // 64)
+        sample_rows = list(range(16, H, 64))           # every 64th row: the whole frame's mix of cheap and dear rays
         t0 = time.perf_counter()
-        oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, wl.positions, W, H, (H - rows1) // 2,
-                           (H - rows1) // 2 + rows1, threads=1, out=scratch)
+        for r0 in sample_rows:
+            oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, wl.positions, W, H, r0, r0 + 1, threads=1,
+                               out=scratch)
         t_one = time.perf_counter() - t0
+        rows1 = len(sample_rows)
         result["cpu_baseline"] = {
             "value": round(rays_per_frame / t_all / 1e6, 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"the same full {W}x{H} frame, {reps} repetitions, OpenMP over rows on {threads} threads",
             "value_1thread": round(rows1 * W * max(1, spp) / t_one / 1e6, 3),
-            "sample_1thread": f"{rows1} centre rows of the same frame on 1 thread",
+            "sample_1thread": f"{rows1} rows (every 64th) of the same frame on 1 thread",
             "bvh_build_seconds": round(wl.build_seconds, 3),
         }
 

@@ -192,7 +192,18 @@ def terrain(n=23, seed=7):
     return _finish(f"terrain{n}", v, f, light_point=[n * 0.5, 6.0, n * 0.5])
 
 
-SCENES = {"cornell": cornell, "atrium": atrium, "city": city, "city_big": city_big}
+def calib(seed=0):
+    """One far-away triangle: a frame traced against it streams the G-buffer and the mask and nothing else
+    (used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE against a known byte count)."""
+    del seed
+    v = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]])
+    sc = _finish("calib", v, np.array([[0, 1, 2]]), light_point=[0.0, 10.0, 0.0])
+    sc.eye = np.array([0.0, 0.0, 0.0], np.float32)
+    sc.target = np.array([0.0, 0.0, -1.0], np.float32)
+    return sc
+
+
+SCENES = {"cornell": cornell, "atrium": atrium, "city": city, "city_big": city_big, "calib": calib}
 
 
 # ------------------------------------------------------------------------------------------------

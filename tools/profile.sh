@@ -19,6 +19,11 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC
   rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $REPO/bench.py --steps 5 --warmup 2 $ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
   echo "pmc$i ($PMC) rc=$?"
 done
+# calibration of FETCH_SIZE / WRITE_SIZE: same dispatch, 1-triangle BVH => reads = the 132.7 MB position stream
+for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/calib_$PMC -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --config calib_4k > $OUT/calib_$PMC.json 2> $OUT/calib_$PMC.err
+  echo "calib $PMC rc=$?"
+done
 cd $REPO
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

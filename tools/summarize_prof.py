@@ -55,6 +55,22 @@ def main():
         derived["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "TCP_TCC_READ_REQ_sum" in c and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
         derived["l1_miss_ratio(read_req/accesses)"] = c["TCP_TCC_READ_REQ_sum"] / max(1.0, c["TCP_TOTAL_CACHE_ACCESSES_sum"])
+    # calibration passes (tools/profile.sh): 1-triangle BVH at the same frame size
+    calib = defaultdict(list)
+    for path, r in rows(os.path.join(out, "calib_*", "**", "*counter_collection.csv")):
+        if "shadowMask" in r.get("Kernel_Name", ""):
+            calib[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if calib:
+        cal = {k: sum(v) / len(v) for k, v in calib.items()}
+        summary["calibration_counters_avg_per_dispatch"] = cal
+        known_read = 3840 * 2160 * 16 + 48        # positions + the 3-vec4 BVH
+        known_write = 3840 * 2160
+        if "FETCH_SIZE" in cal:
+            derived["fetch_factor(known_bytes/FETCH_SIZE_KB*1024)"] = known_read / (cal["FETCH_SIZE"] * 1024)
+            if "FETCH_SIZE" in c:
+                derived["fetch_bytes_calibrated"] = c["FETCH_SIZE"] * 1024 * derived["fetch_factor(known_bytes/FETCH_SIZE_KB*1024)"]
+        if "WRITE_SIZE" in cal:
+            derived["write_factor(known_bytes/WRITE_SIZE_KB*1024)"] = known_write / (cal["WRITE_SIZE"] * 1024)
     summary["derived"] = derived
     print(json.dumps(summary, indent=1))
 
