@@ -266,3 +266,76 @@ def test_error_behaviour(ctx):
         assert fresh.trace_rays(np.zeros((0, 8), np.float32)).size == 0            # empty input is fine
     finally:
         fresh.close()
+
+
+def test_tuning_options_never_change_the_mask(ctx):
+    """Packet size, dissolve window/threshold (16 = always dissolve -> every ray finishes lane-per-ray from the
+    node it stands or waits on; 0 = never), workgroup shape and block order are speed knobs only."""
+    wl = workloads.prepare("atrium", 640, 360)
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                    oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+    ctx.set_bvh(wl.packed)
+    defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel")}
+    try:
+        for kernel in (-1, 3, 4, 5):
+            for budget, share in ((1, 16), (1, 0), (2, 8), (8, 4), (64, 16), (64, 1)):
+                for bw in (1, 4):
+                    ctx.set_option("kernel", kernel)
+                    ctx.set_option("packet_budget", budget)
+                    ctx.set_option("packet_share", share)
+                    ctx.set_option("block_waves", bw)
+                    ctx.set_option("xcd_swizzle", (budget + bw) & 1)
+                    got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+                    assert (got == want).all(), (kernel, budget, share, bw)
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
+
+
+def test_auto_kernel_selection_and_names(ctx):
+    small = workloads.prepare("cornell", 64, 64, via_obj=False)
+    big = workloads.prepare("cornell", 640, 480, via_obj=False)
+    ctx.set_option("kernel", -1)
+    for wl, name in ((small, "shadowMaskKernel<0>"), (big, "shadowMaskPacketKernel<1>")):
+        want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                        oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+        ctx.set_bvh(wl.packed)
+        got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+        assert (got == want).all()
+        assert ctx.last_kernel_name() == name
+
+
+def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
+    """Light inside the room: ray directions of one tile straddle the sign planes (generic form 8).  A blob whose
+    inner boxes have bboxMin > bboxMax on an axis (another producer) must switch the ordered test off."""
+    wl = workloads.prepare("cornell", 320, 320, via_obj=False)
+    packed = wl.packed.copy()
+    N = 2 * wl.prim_count - 1
+    inner = np.nonzero(packed[0:2 * N:2, 3] == 0xFFFFFFFF)[0][5:40]
+    for i in inner:                                                      # swap min.x <-> max.x on some inner nodes
+        packed[2 * i, 0], packed[2 * i + 1, 0] = packed[2 * i + 1, 0], packed[2 * i, 0]
+    for blob, ordered in ((wl.packed, 1), (packed, 0)):
+        want, _, _ = oracle.shadow_mask(blob, wl.constants.as_array(),
+                                        oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+        ctx.set_bvh(blob)
+        assert ctx.get_option("bvh_ordered") == ordered
+        for v in _variants(ctx):
+            ctx.set_option("kernel", v)
+            got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+            assert (got == want).all(), (ordered, v)
+    ctx.set_option("kernel", -1)
+
+
+def test_wave_stats_diagnostics_do_not_touch_the_output(ctx):
+    wl = workloads.prepare("cornell", 256, 256, via_obj=False)
+    ctx.set_bvh(wl.packed)
+    ctx.set_option("kernel", 3)
+    a = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+    waves = (256 // 8) * (256 // 8)
+    ctx.set_option("wave_stats", waves)
+    b = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+    st = ctx.read_wave_stats(waves)
+    ctx.set_option("wave_stats", 0)
+    ctx.set_option("kernel", -1)
+    assert (a == b).all()
+    assert (st[:, 1] > st[:, 0]).all()                                   # every wave stamped start < end
