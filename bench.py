@@ -11,7 +11,7 @@ once per GPU, disjoint output), torch.distributed (gloo) is only the barrier / m
 
   --scaling weak   (default) every rank traces a full frame of its own (rank r = frame r of a camera
                    path), so per-GPU work is fixed and value = N * rays / time.
-  --scaling strong ONE frame, row-striped over the ranks in interleaved 16-row bands (configs[3]).
+  --scaling strong ONE frame, row-striped over the ranks in interleaved 32-row bands, one dispatch per GPU (configs[3]).
 
 Rank 0 prints ONE JSON line.  Before timing, every rank checks its GPU mask against the CPU oracle
 on every pixel of its frame (the correctness gate of SURVEY.md 8d); a mismatch aborts.
@@ -25,6 +25,8 @@ import sys
 import time
 
 import numpy as np
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the oracle's OpenMP workers must not spin beside the launch loop
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -61,6 +63,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line (rank 0): everything else any library prints to fd 1 (gloo announces
+    # its connections there) goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,13 +97,14 @@ def main():
     wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say)
     rays_per_frame = wl.rays
 
-    if args.scaling == "strong" and N > 1:
-        my_rows = partition.stripe_rows(H, N, rank, band=16, interleaved=True)
-    else:
-        my_rows = [(0, H)]
+    BAND = 32
+    striped = args.scaling == "strong" and N > 1
+    my_rows = partition.stripe_rows(H, N, rank, band=BAND, interleaved=True) if striped else [(0, H)]
     my_rays = sum(e - b for b, e in my_rows) * W * max(1, spp)
 
-    ctx = api.ShadowContext(local_rank)
+    # RTS_BENCH_SINGLE_DEVICE=1: rehearsal of the multi-rank flow on a one-GPU box (all ranks share device 0)
+    device = 0 if os.environ.get("RTS_BENCH_SINGLE_DEVICE") else local_rank
+    ctx = api.ShadowContext(device)
     ctx.set_bvh(wl.packed)
     if args.kernel >= 0:
         ctx.set_option("kernel", args.kernel)
@@ -105,9 +113,11 @@ def main():
     ctx.h2d(d_pos, wl.positions)
     ctx.h2d(d_mask, np.zeros((H, W), np.uint8))
 
-    def one_step():
-        for b, e in my_rows:
-            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light, row_begin=b, row_end=e)
+    def one_step():                       # ONE dispatch per step on every rank
+        if striped:
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, BAND, N, rank, light=wl.light)
+        else:
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
 
     # ---- correctness gate: GPU mask == CPU oracle mask, every pixel this rank owns -----------------
     import oracle  # the checker; never on the measured path
@@ -155,9 +165,9 @@ def main():
 
     total_rays = rays_per_frame * (N if args.scaling == "weak" else 1) * args.steps
     value = total_rays / wall / 1e6
-    launches = args.steps * len(my_rows)
+    launches = args.steps
     avg_launch_s = kernel_ms / 1e3 / launches
-    achieved = (alg_bytes_per_step / len(my_rows)) / avg_launch_s / 1e9  # GB/s of algorithmic bytes
+    achieved = alg_bytes_per_step / avg_launch_s / 1e9  # GB/s of algorithmic bytes
     kname = ctx.last_kernel_name()
     traffic = load_traffic(kname, args.config)
 
@@ -174,7 +184,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                     "algorithmic_bytes_per_launch": int(alg_bytes_per_step / len(my_rows)),
+                     "algorithmic_bytes_per_launch": int(alg_bytes_per_step),
                      "avg_launch_ms": round(avg_launch_s * 1e3, 5), "kernel": kname,
                      "note": "algorithmic (cache-oblivious) bytes 32*V+16*L+17/px from the oracle's exact visit counts; "
                              "frac > 1 means the node stream is served from L2/Infinity Cache, not HBM"},
@@ -212,7 +222,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":

@@ -135,6 +135,13 @@ int rts_trace_shadow_mask_device(rts_ctx* ctx, const rts_constants* constants, c
                                  const float* d_positions, uint32_t W, uint32_t H,
                                  uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream);
 
+/* Interleaved row stripes in ONE dispatch (multi-GPU strong scaling): the frame is cut
+ * into bands of band_rows rows (a multiple of 32) dealt round-robin to n_stripes devices; this call
+ * traces the bands stripe, stripe + n_stripes, ... and touches no other row of d_mask. */
+int rts_trace_shadow_mask_stripes_device(rts_ctx* ctx, const rts_constants* constants, const rts_light* light,
+                                         const float* d_positions, uint32_t W, uint32_t H, uint32_t band_rows,
+                                         uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, void* stream);
+
 /* Generic rays (the shader's `Ray`): out[i] = 1 if ray i is NOT occluded.  Host / device forms. */
 int rts_trace_rays(rts_ctx* ctx, const rts_ray* rays, size_t n, uint8_t* out);
 int rts_trace_rays_device(rts_ctx* ctx, const rts_ray* d_rays, size_t n, uint8_t* d_out, void* stream);

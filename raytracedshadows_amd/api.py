@@ -122,6 +122,8 @@ _sig("rts_trace_shadow_mask", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants
      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 _sig("rts_trace_shadow_mask_device", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light),
      C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
+_sig("rts_trace_shadow_mask_stripes_device", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light),
+     C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
 _sig("rts_trace_rays", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("rts_trace_rays_device", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 _sig("rts_device_malloc", C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t)
@@ -258,6 +260,15 @@ class ShadowContext:
         _check(_lib.rts_trace_shadow_mask_device(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width,
                                                  height, row_begin, row_end, C.c_void_p(d_mask),
                                                  C.c_void_p(stream or 0)), "rts_trace_shadow_mask_device")
+
+    def trace_shadow_mask_stripes_device(self, constants, d_positions, width, height, d_mask, band_rows, n_stripes,
+                                         stripe, light=None, stream=None):
+        """One dispatch over the interleaved bands `stripe, stripe + n_stripes, ...` of band_rows rows each."""
+        lp = C.byref(light) if light is not None else None
+        _check(_lib.rts_trace_shadow_mask_stripes_device(self._h, C.byref(constants), lp, C.c_void_p(d_positions),
+                                                         width, height, band_rows, n_stripes, stripe,
+                                                         C.c_void_p(d_mask), C.c_void_p(stream or 0)),
+               "rts_trace_shadow_mask_stripes_device")
 
     def trace_rays(self, rays):
         """``rays``: float32[n, 8] = {o.xyz, tmax, d.xyz, 0}; returns uint8[n] (1 = not occluded)."""

@@ -210,9 +210,9 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     return RTS_ERR_INVALID_ARG;
 }
 
-int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_light* light,
-                                 const float* d_positions, uint32_t W, uint32_t H,
-                                 uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream) {
+static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions,
+                         uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, uint32_t band_rows,
+                         uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, void* stream) {
     if (!c || !k || !d_positions || !d_mask || W == 0 || H == 0 || row_begin > row_end || row_end > H)
         return RTS_ERR_INVALID_ARG;
     if (light && (light->type > RTS_LIGHT_POINT || light->nsamples > 64)) return RTS_ERR_INVALID_ARG;
@@ -224,16 +224,22 @@ int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_l
     p.positions = (const float4*)d_positions;
     p.mask = d_mask;
     p.W = W; p.H = H; p.rowBegin = row_begin; p.rowEnd = row_end;
+    p.bandRows = band_rows; p.nStripes = n_stripes; p.stripe = stripe;
     // V_AUTO: a packet's steps are a dependent chain, so it needs several waves per SIMD to overlap them;
     // a launch with fewer than ~4 waves per SIMD is faster lane-per-ray.  (Bigger packets, V_PACKET2/4, were
     // measured slower or equal on every BASELINE config and are kept as selectable variants only.)
     int variant = c->variant;
-    const uint64_t pixels = (uint64_t)W * (row_end - row_begin);
+    uint32_t rows = row_end - row_begin;
+    if (n_stripes > 1) {                        // virtual rows = whole owned bands (partial last band guarded in-kernel)
+        const uint32_t bands = (H + band_rows - 1) / band_rows;
+        rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows;
+    }
+    const uint64_t pixels = (uint64_t)W * rows;
     if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_STRAIGHT;
     uint32_t bw, bh;
     rts::tileShape(variant, c->blockWaves, &bw, &bh);
     p.blocksX = (W + bw - 1) / bw;
-    p.blocksY = (row_end - row_begin + bh - 1) / bh;
+    p.blocksY = (rows + bh - 1) / bh;
     p.nBlocks = p.blocksX * p.blocksY;
     p.swizzle = c->swizzle ? 1u : 0u;
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
@@ -252,6 +258,26 @@ int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_l
     c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
     return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream));
+}
+
+int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_light* light,
+                                 const float* d_positions, uint32_t W, uint32_t H,
+                                 uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream) {
+    return traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, 0, 1, 0, d_mask, stream);
+}
+
+int rts_trace_shadow_mask_stripes_device(rts_ctx* c, const rts_constants* k, const rts_light* light,
+                                         const float* d_positions, uint32_t W, uint32_t H, uint32_t band_rows,
+                                         uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, void* stream) {
+    if (band_rows == 0 || band_rows % 32 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
+    if (n_stripes == 1) return traceMaskImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, stream);
+    // rows this stripe owns: whole bands stripe, stripe+n, ... (the last one may be cut by H)
+    const uint32_t bands = (H + band_rows - 1) / band_rows;
+    uint32_t owned = 0;
+    for (uint32_t b = stripe; b < bands; b += n_stripes) owned += (b + 1) * band_rows <= H ? band_rows : H - b * band_rows;
+    if (owned == 0) return RTS_OK;
+    // dispatch `owned` virtual rows; the kernel maps them onto the frame (ownedRow) and guards with row < H
+    return traceMaskImpl(c, k, light, d_positions, W, H, 0, H, band_rows, n_stripes, stripe, d_mask, stream);
 }
 
 int rts_trace_shadow_mask(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* positions,

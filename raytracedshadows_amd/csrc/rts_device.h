@@ -26,6 +26,7 @@ struct TraceParams {
     const float4* positions;  // W x H RGBA32F, camera-relative (device)
     uint8_t* mask;            // W x H bytes (device)
     uint32_t W, H, rowBegin, rowEnd;
+    uint32_t bandRows, nStripes, stripe;   // interleaved stripes (nStripes <= 1: plain rowBegin..rowEnd)
     uint32_t blocksX, blocksY, nBlocks, gridBlocks, swizzle;
     float cam[3];
     uint32_t lightType, nsamples;

@@ -425,6 +425,15 @@ __device__ __forceinline__ bool blockToXY(const TraceParams& p, uint32_t bid, ui
 }
 
 
+// Row of the frame for the v-th row this dispatch owns.  Plain stripe: rowBegin + v.  Interleaved
+// stripes (multi-GPU): bands of bandRows rows dealt round-robin, this device owns every
+// nStripes-th band starting with band `stripe`.
+__device__ __forceinline__ uint32_t ownedRow(const TraceParams& p, uint32_t v) {
+    if (p.nStripes <= 1u) return p.rowBegin + v;
+    const uint32_t band = v / p.bandRows;
+    return (band * p.nStripes + p.stripe) * p.bandRows + (v - band * p.bandRows);
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
     if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = p.rowBegin + by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t y = ownedRow(p, by * 16u + (wave >> 1) * 8u + (lane >> 3));
     const bool live = (x < p.W) && (y < p.rowEnd);
     const size_t pix = (size_t)y * p.W + x;
 
@@ -470,13 +479,13 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
     if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);
-    const uint32_t y0 = p.rowBegin + (WPB == 4 ? by * (2u * TH) + (wave >> 1) * TH : by * TH) + (lane >> 3);
+    const uint32_t v0 = (WPB == 4 ? by * (2u * TH) + (wave >> 1) * TH : by * TH) + (lane >> 3);
     bool live[K];
     size_t pix[K];
     F3 rel[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t x = x0 + (k & 1) * 8u, y = y0 + (k >> 1) * 8u;
+        const uint32_t x = x0 + (k & 1) * 8u, y = ownedRow(p, v0 + (k >> 1) * 8u);
         live[k] = (x < p.W) && (y < p.rowEnd);
         pix[k] = (size_t)y * p.W + x;
         rel[k] = F3{ 0.f, 0.f, 0.f };

@@ -33,10 +33,11 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
     say(f"scene {sc.name}: {sc.triangle_count} triangles generated in {time.time() - t0:.2f}s")
     if via_obj:
         t0 = time.time()
-        path = os.path.join(scenes.cache_dir(), f"{sc.name}.obj")
+        path = os.path.join(scenes.cache_dir(), f"{sc.name}_{os.getpid()}.obj")   # one file per process (ranks)
         sc.write_obj(path)
         verts, indices, lo, hi = api.obj_load(path)
         say(f"obj written + parsed in {time.time() - t0:.2f}s ({os.path.getsize(path) / 1e6:.1f} MB)")
+        os.remove(path)
     else:
         verts, indices = sc.flat()
     prim_count = verts.shape[0] // 3

@@ -339,3 +339,45 @@ def test_wave_stats_diagnostics_do_not_touch_the_output(ctx):
     ctx.set_option("kernel", -1)
     assert (a == b).all()
     assert (st[:, 1] > st[:, 0]).all()                                   # every wave stamped start < end
+
+
+def test_interleaved_stripes_single_dispatch(ctx):
+    """configs[3], the form bench.py --scaling strong uses: each device traces its interleaved 32-row bands in
+    ONE dispatch.  All stripes of a partition, traced one after the other into one mask, give the full frame;
+    a single stripe touches only its own rows."""
+    wl = workloads.prepare("atrium", 648, 500)                       # 500 rows: the last band is ragged
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                    oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+    ctx.set_bvh(wl.packed)
+    W, H = wl.W, wl.H
+    d_pos = ctx.malloc(wl.positions.nbytes)
+    d_mask = ctx.malloc(W * H)
+    ctx.h2d(d_pos, wl.positions)
+    try:
+        for kernel in (-1, 0, 3, 5):
+            ctx.set_option("kernel", kernel)
+            for n in (1, 2, 3, 8):
+                got = np.full((H, W), 7, np.uint8)
+                ctx.h2d(d_mask, got)
+                for stripe in range(n):
+                    ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, stripe, light=wl.light)
+                ctx.synchronize()
+                ctx.d2h(got, d_mask)
+                assert (got == want).all(), (kernel, n)
+            got = np.full((H, W), 7, np.uint8)
+            ctx.h2d(d_mask, got)
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 4, 1, light=wl.light)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            own = np.zeros(H, bool)
+            for b, e in partition.stripe_rows(H, 4, 1, band=32, interleaved=True):
+                own[b:e] = True
+            assert (got[own] == want[own]).all() and (got[~own] == 7).all()
+        with pytest.raises(api.RtsError):
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 24, 2, 0)      # band not a multiple of 32
+        with pytest.raises(api.RtsError):
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 2, 2)      # stripe out of range
+    finally:
+        ctx.set_option("kernel", -1)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
