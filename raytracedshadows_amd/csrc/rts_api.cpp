@@ -171,7 +171,7 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     if (count * 16 >= (1ull << 32)) return RTS_ERR_BAD_BVH;            // 32-bit byte offsets on the device
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
-    RTS_HIP(hipMalloc(&c->d_bvh, count * 16));
+    RTS_HIP(hipMalloc(&c->d_bvh, count * 16 + 64));   // + slack: the prefetching packet loop reads one node ahead
     RTS_HIP(hipMemcpy(c->d_bvh, packed, count * 16, hipMemcpyHostToDevice));
     c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
     return RTS_OK;

@@ -12,6 +12,7 @@ enum Variant {
     V_PACKET = 3,      // wave (8x8 px) walks the union of its rays' paths; nodes via scalar loads
     V_PACKET2 = 4,     // same, 2 rays per lane (16x8 px per wave)
     V_PACKET4 = 5,     // same, 4 rays per lane (16x16 px per wave)
+    V_PACKET_PF = 6,   // V_PACKET with the sequential successor node prefetched into a second SGPR set
     V_COUNT,
     V_AUTO = -1        // packet for big launches, straight for small ones
 };

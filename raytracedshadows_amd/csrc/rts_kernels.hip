@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 // (v_min/v_max per axis) runs, and waves with an unsafe ray go lane-per-ray with the EXACT form.
 #include "rts_packet_asm.inc"
 
-template <int K>
+template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], int32_t* sideStepsLeft = nullptr) {
     const ConstNodePtr nodes = (ConstNodePtr)(uintptr_t)p.bvh;
@@ -346,7 +346,10 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
         for (int k = 0; k < K; ++k)
             members[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(members[k] >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)members[k]);
-        leaf = packetDescend(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;
+        if constexpr (PREFETCH && K == 1)
+            leaf = packetDescendPrefetch(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;
+        else
+            leaf = packetDescend(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;
         if (leaf) {
             // the packet stands on a leaf: one triangle, tested by the rays that are here
             const u32x8 n = nodes[cur];
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // 8x8 sub-tiles of its wave tile), a 256-thread block is 2x2 wave tiles.
 // WPB = waves per block: 4 (block = 2x2 wave tiles) or 1 (block = one wave tile, so that a finished wave
 // frees its slot without waiting for three siblings).
-template <int K, int WPB>
+template <int K, int WPB, bool PREFETCH = false>
 __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p) {
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx, by;
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
         bool occluded[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
-        traversePacket<K>(p, bvh, r, live, occluded, &left);
+        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, &left);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -565,6 +568,7 @@ const char* kernelName(int variant, bool mask) {
     case V_PACKET: return mask ? "shadowMaskPacketKernel<1>" : "traceRaysKernel<3>";
     case V_PACKET2: return mask ? "shadowMaskPacketKernel<2>" : "traceRaysKernel<3>";
     case V_PACKET4: return mask ? "shadowMaskPacketKernel<4>" : "traceRaysKernel<3>";
+    case V_PACKET_PF: return mask ? "shadowMaskPacketKernel<1,pf>" : "traceRaysKernel<3>";
     }
     return "?";
 }
@@ -583,6 +587,7 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, 0, stream, p); break;
         case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1>), grid, b1, 0, stream, p); break;
         case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1>), grid, b1, 0, stream, p); break;
+        case V_PACKET_PF: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true>), grid, b1, 0, stream, p); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -594,6 +599,7 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4>), grid, block, 0, stream, p); break;
     case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4>), grid, block, 0, stream, p); break;
     case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4>), grid, block, 0, stream, p); break;
+    case V_PACKET_PF: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -605,7 +611,7 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
     case V_STRAIGHT: hipLaunchKernelGGL(traceRaysKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(traceRaysKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(traceRaysKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
-    case V_PACKET: case V_PACKET2: case V_PACKET4:
+    case V_PACKET: case V_PACKET2: case V_PACKET4: case V_PACKET_PF:
         hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }

@@ -127,8 +127,79 @@ def loop(K, form):
     return L
 
 
-def emit_asm(K, form, ind):
-    lines = loop(K, form)
+def loop_prefetch(form):
+    """K = 1 with the sequential successor prefetched: s[40:47] = node `cur`, s[56:63] = node cur+1 (the down-step
+    target), loaded while `cur` is being tested.  Scalar loads may return out of order, so every wait is
+    lgkmcnt(0), and the prefetch is drained before its registers are re-targeted or the asm is left."""
+    k = 0
+    test = test_generic(k) if form == 8 else test_ordered(k, form)
+    r = "s[54:55]"
+    L = ["s_lshl_b32 s52, %[cur], 5",
+         "2:",                                           # (re)load: current node + its sequential successor
+         "s_load_dwordx8 s[40:47], %[base], s52",
+         "s_add_u32 s53, s52, 32",
+         "s_load_dwordx8 s[56:63], %[base], s53",
+         "s_waitcnt lgkmcnt(0)",
+         "3:",                                           # s[40:47] valid; a prefetch into s[56:63] may be in flight
+         "s_cmp_lg_u32 s43, -1",
+         "s_cbranch_scc1 9f"]
+    L += test
+    L += [f"s_andn2_b64 s[50:51], %[m0], {r}",
+          "s_cbranch_scc0 10f",
+          "s_mov_b64 s[48:49], exec",
+          "s_mov_b64 exec, s[50:51]",
+          "v_mov_b32 %[w0], s47",
+          "s_mov_b64 exec, s[48:49]",
+          "10:",
+          f"s_and_b64 %[m0], %[m0], {r}",
+          "s_cbranch_scc0 4f",
+          # down-step: the successor is (being) loaded already
+          "s_add_u32 s52, s52, 32",
+          "s_waitcnt lgkmcnt(0)",
+          "s_mov_b64 s[40:41], s[56:57]",
+          "s_mov_b64 s[42:43], s[58:59]",
+          "s_mov_b64 s[44:45], s[60:61]",
+          "s_mov_b64 s[46:47], s[62:63]",
+          "s_add_u32 s53, s52, 32",
+          "s_load_dwordx8 s[56:63], %[base], s53",      # prefetch the next one; overlaps the test of this node
+          "s_branch 3b",
+          "4:",                                          # side-step
+          "s_waitcnt lgkmcnt(0)",                        # drain the stale prefetch before re-targeting s[56:63]
+          "s_lshl_b32 s52, s47, 5",
+          "s_cmp_eq_u32 s47, -1",
+          "s_cbranch_scc1 6f",
+          "v_cmp_eq_u32 %[m0], s47, %[w0]",
+          "s_bcnt1_i32_b64 s50, %[m0]",
+          "s_add_u32 %[acc], %[acc], s50",
+          "s_sub_u32 %[budget], %[budget], 1",
+          "s_cbranch_scc0 2b",
+          "v_cmp_ne_u32 s[48:49], -1, %[w0]",
+          "s_or_b64 s[48:49], s[48:49], %[m0]",
+          "s_bcnt1_i32_b64 s51, s[48:49]",
+          "s_mul_i32 s51, s51, %[thr]",
+          "s_lshl_b32 s50, %[acc], 4",
+          "s_mov_b32 %[acc], 0",
+          "s_mov_b32 %[budget], %[window]",
+          "s_cmp_lt_u32 s50, s51",
+          "s_cbranch_scc0 2b",
+          "8:",
+          "s_mov_b32 %[leaf], 0",
+          "s_lshr_b32 %[cur], s52, 5",
+          "s_branch 7f",
+          "6:",
+          "s_mov_b32 %[leaf], 0",
+          "s_mov_b32 %[cur], -1",
+          "s_branch 7f",
+          "9:",
+          "s_mov_b32 %[leaf], 1",
+          "s_lshr_b32 %[cur], s52, 5",
+          "7:",
+          "s_waitcnt lgkmcnt(0)"]                        # nothing of ours may land in SGPRs after the asm ends
+    return L
+
+
+def emit_asm(K, form, ind, prefetch=False):
+    lines = loop_prefetch(form) if prefetch else loop(K, form)
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
     outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
     outs += [f'[m{k}] "+s"(members[{k}])' for k in range(K)]
@@ -137,7 +208,8 @@ def emit_asm(K, form, ind):
     ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
     for k in range(K):
         ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
-    clob = [f'"s{i}"' for i in list(range(40, 53)) + list(range(54, 54 + 2 * K))] + ['"vcc"', '"scc"']
+    regs = list(range(40, 54)) + list(range(54, 64)) if prefetch else list(range(40, 53)) + list(range(54, 54 + 2 * K))
+    clob = [f'"s{i}"' for i in regs] + ['"vcc"', '"scc"']
     return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
             f"{ind}    : {', '.join(clob)});\n")
 
@@ -166,6 +238,21 @@ def main():
         o.append("    return leaf;")
         o.append("}")
         o.append("")
+    o.append("// K = 1 with the sequential successor node prefetched into a second SGPR set (see loop_prefetch).")
+    o.append("__device__ __forceinline__ uint32_t packetDescendPrefetch(uint32_t form, const void* base, const Ray (&r)[1],")
+    o.append("                                                        uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
+    o.append("                                                        int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
+    o.append("    uint32_t leaf;")
+    o.append("    float t0, t1, t2, t3, t4, t5, t6;")
+    o.append("    switch (form) {")
+    for form in range(9):
+        o.append(f"    case {form}:" if form < 8 else "    default:")
+        o.append(emit_asm(1, form, "        ", prefetch=True).rstrip("\n"))
+        o.append("        break;")
+    o.append("    }")
+    o.append("    return leaf;")
+    o.append("}")
+    o.append("")
     open(OUT, "w").write("\n".join(o))
     print("wrote", OUT, sum(1 for _ in open(OUT)), "lines")
 
