@@ -27,6 +27,24 @@ int rtsh_primary_positions(const rts_vec4u* packed, size_t count_vec4, const flo
                            const float target[3], float fovy, uint32_t W, uint32_t H,
                            float* positions, uint64_t* hit_count, int threads);
 
+/* Same plus the normal target (Model.frag:35,38: RGBA, face normal turned towards the viewer; 0 = background).
+ * normals may be NULL. */
+int rtsh_primary_gbuffer(const rts_vec4u* packed, size_t count_vec4, const float eye[3], const float target[3],
+                         float fovy, uint32_t W, uint32_t H, float* positions, float* normals,
+                         uint64_t* hit_count, int threads);
+
+/* The same pass on the GPU: traces through the BVH already uploaded to `ctx`, writes DEVICE
+ * buffers (W*H*4 floats each, d_normals may be NULL), asynchronous on `stream`.  Produces the same bits as the host
+ * version (shared code, same FP rules). */
+int rtsh_primary_gbuffer_device(rts_ctx* ctx, const float eye[3], const float target[3], float fovy,
+                                uint32_t W, uint32_t H, float* d_positions, float* d_normals, void* stream);
+
+/* Combine pass (Source/Shaders/Combine.frag:18-37 with the default white material):
+ * rgb[W*H*3] = 255 * (1.25*max(0,N.L)*mask/samples + 0.15 + 0.05*(1 - max(0, N.-cameraDirection))), 0 where the
+ * normal is 0.  light == NULL: directional light from constants->lightDirection; positions needed for point lights. */
+int rtsh_combine(const rts_constants* constants, const rts_light* light, const float* positions, const float* normals,
+                 const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb);
+
 /* OBJ ingest.  rtsh_obj_load parses `path` and expands it to the reference's flat
  * Vertex stream: 8 floats per vertex (position.xyz, normal.xyz, texcoord.uv), indices[i] = i.
  * Call with vertices == NULL to query *vertex_count (3 per triangle) first.  Returns RTS_OK,

@@ -138,6 +138,12 @@ _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
      C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
+_sig("rtsh_primary_gbuffer", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
+     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
+_sig("rtsh_primary_gbuffer_device", C.c_int, C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p,
+     C.c_void_p, C.c_void_p)
+_sig("rtsh_combine", C.c_int, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_uint32, C.c_uint32, C.c_void_p)
 _sig("rtsh_obj_load", C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, _u32p, _f32p, _f32p)
 _sig("rtsh_obj_parse_float", C.c_float, C.c_char_p, C.POINTER(C.c_int))
 
@@ -327,6 +333,76 @@ def primary_positions(packed, eye, target, fovy, width, height, threads=0):
     _check(_lib.rtsh_primary_positions(_ptr(packed), packed.shape[0], e, t, fovy, width, height, _ptr(pos),
                                        C.byref(hits), threads), "rtsh_primary_positions")
     return pos, int(hits.value)
+
+
+def primary_gbuffer(packed, eye, target, fovy, width, height, threads=0):
+    """Positions + normals targets (host)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1, 4)
+    pos = np.zeros((height, width, 4), dtype=np.float32)
+    nrm = np.zeros((height, width, 4), dtype=np.float32)
+    e = (C.c_float * 3)(*[float(x) for x in eye])
+    t = (C.c_float * 3)(*[float(x) for x in target])
+    hits = C.c_uint64(0)
+    _check(_lib.rtsh_primary_gbuffer(_ptr(packed), packed.shape[0], e, t, fovy, width, height, _ptr(pos), _ptr(nrm),
+                                     C.byref(hits), threads), "rtsh_primary_gbuffer")
+    return pos, nrm, int(hits.value)
+
+
+def primary_gbuffer_device(ctx, eye, target, fovy, width, height, d_positions, d_normals=None, stream=None):
+    """The G-buffer pass on the GPU, through the BVH uploaded to `ctx` (device pointers, asynchronous)."""
+    e = (C.c_float * 3)(*[float(x) for x in eye])
+    t = (C.c_float * 3)(*[float(x) for x in target])
+    _check(_lib.rtsh_primary_gbuffer_device(ctx.handle, e, t, fovy, width, height, C.c_void_p(d_positions),
+                                            C.c_void_p(d_normals or 0), C.c_void_p(stream or 0)),
+           "rtsh_primary_gbuffer_device")
+
+
+def combine(constants, light, positions, normals, mask):
+    """Combine.frag on the host: uint8[H, W, 3]."""
+    H, W = mask.shape
+    normals = np.ascontiguousarray(normals, np.float32)
+    positions = np.ascontiguousarray(positions, np.float32) if positions is not None else None
+    mask = np.ascontiguousarray(mask, np.uint8)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    lp = C.byref(light) if light is not None else None
+    _check(_lib.rtsh_combine(C.byref(constants), lp, _ptr(positions) if positions is not None else None, _ptr(normals),
+                             _ptr(mask), W, H, _ptr(rgb)), "rtsh_combine")
+    return rgb
+
+
+def write_ppm(path, rgb):
+    """Binary PPM (P6) image dump."""
+    H, W, _ = rgb.shape
+    with open(path, "wb") as fh:
+        fh.write(f"P6\n{W} {H}\n255\n".encode())
+        fh.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+    return path
+
+
+_BLOB_MAGIC = b"RTSBVH01"
+
+
+def save_bvh(path, packed):
+    """Serialises a packed node stream (cacheable scenes): magic, vec4 count, raw little-endian bytes."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1, 4)
+    bvh_validate(packed)
+    with open(path, "wb") as fh:
+        fh.write(_BLOB_MAGIC)
+        fh.write(np.array([packed.shape[0]], np.uint64).tobytes())
+        fh.write(packed.tobytes())
+    return path
+
+
+def load_bvh(path):
+    with open(path, "rb") as fh:
+        if fh.read(8) != _BLOB_MAGIC:
+            raise RtsError(5, f"load_bvh: {path} is not a packed-BVH blob")
+        n = int(np.frombuffer(fh.read(8), np.uint64)[0])
+        packed = np.frombuffer(fh.read(n * 16), np.uint32).reshape(-1, 4).copy()
+    if packed.shape[0] != n:
+        raise RtsError(5, f"load_bvh: {path} is truncated")
+    bvh_validate(packed)
+    return packed
 
 
 def obj_load(path):

@@ -381,6 +381,13 @@ int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
 }
 const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel.c_str() : ""; }
 
+// used by the harness (rts_primary.hip): the device copy of the packed stream, NULL before rts_ctx_set_bvh
+const void* rts_ctx_device_bvh(rts_ctx* c) {
+    if (!c) return nullptr;
+    (void)hipSetDevice(c->device);
+    return c->d_bvh;
+}
+
 int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {
     if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));

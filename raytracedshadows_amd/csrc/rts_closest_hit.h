@@ -1,0 +1,99 @@
+// Harness: closest hit of one primary ray through the packed BVH, shared verbatim by the
+// host (rts_scene.cpp) and device (rts_primary.hip) G-buffer generators so that both produce the same bits.
+// Stackless walk over the miss links; boxes are culled against the best t so far.  Input synthesis only -- this is
+// not the path under test (the reference rasterises its G-buffer, Source/Shaders/Model.vert/.frag).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define RTS_HD __host__ __device__ inline
+#else
+#define RTS_HD inline
+#endif
+
+namespace rts_harness {
+
+struct V3 { float x, y, z; };
+RTS_HD V3 sub(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+RTS_HD V3 add(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+RTS_HD V3 mul(V3 a, float s) { return V3{ a.x * s, a.y * s, a.z * s }; }
+RTS_HD V3 cross(V3 a, V3 b) { return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+RTS_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RTS_HD float asFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+struct Camera { V3 eye, fwd, right, up; float tanHalf, aspect; };
+
+struct Hit { float t; uint32_t leaf; };   // leaf = node index of the hit triangle, 0xFFFFFFFF = none
+
+RTS_HD V3 primaryDirection(const Camera& c, uint32_t x, uint32_t y, uint32_t W, uint32_t H) {
+    float sx = (((float)x + 0.5f) / (float)W * 2.0f - 1.0f) * c.tanHalf * c.aspect;
+    float sy = (1.0f - ((float)y + 0.5f) / (float)H * 2.0f) * c.tanHalf;
+    return add(add(c.fwd, mul(c.right, sx)), mul(c.up, sy));
+}
+
+RTS_HD Hit closestHit(const uint32_t* bvh, V3 o, V3 d) {
+    const float inf = asFloat(0x7F800000u);
+    const V3 inv{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    Hit best{ inf, 0xFFFFFFFFu };
+    uint32_t node = 0;
+    while (node != 0xFFFFFFFFu) {
+        const uint32_t* a = bvh + (size_t)node * 8;
+        const uint32_t* b = a + 4;
+        if (a[3] != 0xFFFFFFFFu) {
+            const uint32_t* t = bvh + (size_t)a[3] * 4;
+            V3 e0{ asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, e1{ asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
+            V3 v0{ asFloat(t[0]), asFloat(t[1]), asFloat(t[2]) };
+            V3 s1 = cross(d, e1);
+            float det = dot(s1, e0);
+            if (det != 0.0f) {
+                float invd = 1.0f / det;
+                V3 dd = sub(o, v0);
+                float b1 = dot(dd, s1) * invd;
+                V3 s2 = cross(dd, e0);
+                float b2 = dot(d, s2) * invd;
+                float tt = dot(e1, s2) * invd;
+                if (b1 >= 0.0f && b2 >= 0.0f && b1 + b2 <= 1.0f && tt > 0.0f && tt < best.t) { best.t = tt; best.leaf = node; }
+            }
+        } else {
+            float lo[3] = { asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, hi[3] = { asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
+            float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
+            float t0 = 0.0f, t1 = best.t;
+            for (int k = 0; k < 3; ++k) {
+                float f = (hi[k] - oo[k]) * ii[k], n = (lo[k] - oo[k]) * ii[k];
+                float mx = f > n ? f : n, mn = f > n ? n : f;
+                if (mx < t1) t1 = mx;      // NaN (0*inf) compares false: the slab is ignored
+                if (mn > t0) t0 = mn;
+            }
+            if (t1 >= t0) { ++node; continue; }
+        }
+        node = b[3];
+    }
+    return best;
+}
+
+// G-buffer texel: camera-relative position (Model.frag:39) and the face normal turned towards the viewer
+// (Model.frag:38 `gl_FrontFacing ? n : -n`; the harness has no vertex normals, so the geometric one is used).
+RTS_HD void shadePixel(const uint32_t* bvh, const Camera& c, uint32_t x, uint32_t y, uint32_t W, uint32_t H,
+                       float* position4, float* normal4) {
+    V3 d = primaryDirection(c, x, y, W, H);
+    Hit h = closestHit(bvh, c.eye, d);
+    if (h.leaf == 0xFFFFFFFFu) {
+        position4[0] = position4[1] = position4[2] = position4[3] = 0.0f;       // clear value (background)
+        if (normal4) normal4[0] = normal4[1] = normal4[2] = normal4[3] = 0.0f;
+        return;
+    }
+    V3 rel = mul(d, h.t);
+    position4[0] = rel.x; position4[1] = rel.y; position4[2] = rel.z; position4[3] = 1.0f;
+    if (normal4) {
+        const uint32_t* a = bvh + (size_t)h.leaf * 8;
+        V3 e0{ asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, e1{ asFloat(a[4]), asFloat(a[5]), asFloat(a[6]) };
+        V3 n = cross(e0, e1);
+        float len2 = dot(n, n);
+        float s = len2 > 0.0f ? 1.0f / __builtin_sqrtf(len2) : 0.0f;
+        if (dot(n, d) > 0.0f) s = -s;
+        normal4[0] = n.x * s; normal4[1] = n.y * s; normal4[2] = n.z * s; normal4[3] = 0.0f;
+    }
+}
+
+} // namespace rts_harness

@@ -1,10 +1,11 @@
-// Harness: synthesises the G-buffer position target the shadow kernel consumes
-// (Source/Shaders/Model.frag:35,39 writes worldPosition - cameraPosition into an RGBA32F target;
-// Source/RayTracedShadows.cpp:385-387).  Here: closest hit of one pinhole ray per pixel centre
-// through the same packed BVH, on the host, multi-threaded.
-// This is input synthesis, not the path under test: both the GPU kernels and the CPU oracle are fed
-// the buffer this file produces.
+// Harness: synthesises the G-buffer targets the shadow kernel and the combine pass consume
+// (Source/Shaders/Model.frag:35-39 writes normal and worldPosition - cameraPosition; targets created at
+// Source/RayTracedShadows.cpp:378-387) and evaluates the combine pass (Source/Shaders/Combine.frag:18-37).
+// Host versions, multi-threaded; the device version of the G-buffer pass is rts_primary.hip.
+// This is input synthesis / presentation, not the path under test: both the GPU kernels and the CPU oracle are fed
+// the buffers this file produces.
 #include "../../include/rts_scene.h"
+#include "rts_closest_hit.h"
 
 #include <atomic>
 #include <cmath>
@@ -12,74 +13,35 @@
 #include <thread>
 #include <vector>
 
-namespace {
+using namespace rts_harness;
 
-struct V3 { float x, y, z; };
-inline V3 operator-(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
-inline V3 operator+(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
-inline V3 operator*(V3 a, float s) { return V3{ a.x * s, a.y * s, a.z * s }; }
-inline V3 cross(V3 a, V3 b) { return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
-inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline V3 normalize(V3 a) { float l = std::sqrt(dot(a, a)); return l > 0 ? a * (1.0f / l) : a; }
-inline float asF(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-
-// Closest hit along o + t*d, t in (0, inf).  Stackless walk over the miss links; boxes are culled
-// against the best t so far.
-float closestHit(const rts_vec4u* bvh, V3 o, V3 d) {
-    const V3 inv{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
-    float best = INFINITY;
-    uint32_t node = 0;
-    while (node != 0xFFFFFFFFu) {
-        const rts_vec4u& a = bvh[2 * (size_t)node];
-        const rts_vec4u& b = bvh[2 * (size_t)node + 1];
-        if (a.d != 0xFFFFFFFFu) {
-            const rts_vec4u& t = bvh[a.d];
-            V3 e0{ asF(a.a), asF(a.b), asF(a.c) }, e1{ asF(b.a), asF(b.b), asF(b.c) }, v0{ asF(t.a), asF(t.b), asF(t.c) };
-            V3 s1 = cross(d, e1);
-            float det = dot(s1, e0);
-            if (det != 0.0f) {
-                float invd = 1.0f / det;
-                V3 dd = o - v0;
-                float b1 = dot(dd, s1) * invd;
-                V3 s2 = cross(dd, e0);
-                float b2 = dot(d, s2) * invd;
-                float tt = dot(e1, s2) * invd;
-                if (b1 >= 0.0f && b2 >= 0.0f && b1 + b2 <= 1.0f && tt > 0.0f && tt < best) best = tt;
-            }
-        } else {
-            float lo[3] = { asF(a.a), asF(a.b), asF(a.c) }, hi[3] = { asF(b.a), asF(b.b), asF(b.c) };
-            float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
-            float t0 = 0.0f, t1 = best;
-            for (int k = 0; k < 3; ++k) {
-                float f = (hi[k] - oo[k]) * ii[k], n = (lo[k] - oo[k]) * ii[k];
-                float mx = f > n ? f : n, mn = f > n ? n : f;
-                if (mx < t1) t1 = mx;     // NaN (0*inf) compares false: slab ignored
-                if (mn > t0) t0 = mn;
-            }
-            if (t1 >= t0) { ++node; continue; }
-        }
-        node = b.d;
-    }
-    return best;
+namespace rts_harness {
+// Pinhole camera as the reference sets it up (RayTracedShadows.cpp:238-242): vertical fov, lookAt, +Y up.
+Camera makeCamera(const float eye[3], const float target[3], float fovy, uint32_t W, uint32_t H) {
+    Camera c;
+    c.eye = V3{ eye[0], eye[1], eye[2] };
+    V3 f = sub(V3{ target[0], target[1], target[2] }, c.eye);
+    float fl = std::sqrt(dot(f, f));
+    c.fwd = fl > 0 ? mul(f, 1.0f / fl) : V3{ 0, 0, -1 };
+    V3 r = cross(V3{ 0, 1, 0 }, c.fwd);
+    float rl = std::sqrt(dot(r, r));
+    c.right = rl > 0 ? mul(r, 1.0f / rl) : V3{ 1, 0, 0 };
+    c.up = cross(c.fwd, c.right);
+    c.tanHalf = std::tan(fovy * 0.5f);
+    c.aspect = (float)W / (float)H;
+    return c;
 }
+} // namespace rts_harness
 
-} // namespace
-
-extern "C" int rtsh_primary_positions(const rts_vec4u* packed, size_t count, const float eye[3],
-                                      const float target[3], float fovy, uint32_t W, uint32_t H,
-                                      float* positions, uint64_t* hit_count, int threads) {
+extern "C" int rtsh_primary_gbuffer(const rts_vec4u* packed, size_t count, const float eye[3], const float target[3],
+                                    float fovy, uint32_t W, uint32_t H, float* positions, float* normals,
+                                    uint64_t* hit_count, int threads) {
     if (!packed || !eye || !target || !positions || W == 0 || H == 0) return RTS_ERR_INVALID_ARG;
     uint32_t P = 0;
     int s = rts_bvh_validate(packed, count, &P);
     if (s != RTS_OK) return s;
-    const V3 e{ eye[0], eye[1], eye[2] }, tg{ target[0], target[1], target[2] };
-    const V3 fwd = normalize(tg - e);
-    V3 right = cross(V3{ 0, 1, 0 }, fwd);
-    if (dot(right, right) == 0.0f) right = V3{ 1, 0, 0 };
-    right = normalize(right);
-    const V3 up = cross(fwd, right);
-    const float th = std::tan(fovy * 0.5f), aspect = (float)W / (float)H;
-
+    const Camera cam = makeCamera(eye, target, fovy, W, H);
+    const uint32_t* bvh = (const uint32_t*)packed;
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
@@ -91,13 +53,9 @@ extern "C" int rtsh_primary_positions(const rts_vec4u* packed, size_t count, con
             uint32_t y = nextRow.fetch_add(1);
             if (y >= H) break;
             for (uint32_t x = 0; x < W; ++x) {
-                float sx = (((float)x + 0.5f) / (float)W * 2.0f - 1.0f) * th * aspect;
-                float sy = (1.0f - ((float)y + 0.5f) / (float)H * 2.0f) * th;
-                V3 d = fwd + right * sx + up * sy;
-                float t = closestHit(packed, e, d);
-                float* o = positions + ((size_t)y * W + x) * 4;
-                if (t < INFINITY) { V3 rel = d * t; o[0] = rel.x; o[1] = rel.y; o[2] = rel.z; o[3] = 1.0f; ++local; }
-                else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+                size_t i = ((size_t)y * W + x) * 4;
+                shadePixel(bvh, cam, x, y, W, H, positions + i, normals ? normals + i : nullptr);
+                local += positions[i + 3] != 0.0f;
             }
         }
         hits.fetch_add(local);
@@ -107,5 +65,48 @@ extern "C" int rtsh_primary_positions(const rts_vec4u* packed, size_t count, con
     work();
     for (auto& t : pool) t.join();
     if (hit_count) *hit_count = hits.load();
+    return RTS_OK;
+}
+
+extern "C" int rtsh_primary_positions(const rts_vec4u* packed, size_t count, const float eye[3], const float target[3],
+                                      float fovy, uint32_t W, uint32_t H, float* positions, uint64_t* hit_count,
+                                      int threads) {
+    return rtsh_primary_gbuffer(packed, count, eye, target, fovy, W, H, positions, nullptr, hit_count, threads);
+}
+
+// Combine.frag:18-37 with baseColor = 1 (the default white material, RayTracedShadows.cpp:1013-1018):
+//   direct  = 1.25 * max(0, N.L) * shadowMask            shadowMask = mask / samples
+//   ambient = 0.15 + 0.05 * (1 - max(0, N.(-cameraDirection)))
+//   pixel discarded (left 0) where the normal is 0 (background)
+// L = constants.lightDirection for a directional light; for the point-light extension L = normalize(light - P).
+extern "C" int rtsh_combine(const rts_constants* k, const rts_light* light, const float* positions, const float* normals,
+                            const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb) {
+    if (!k || !normals || !mask || !rgb || W == 0 || H == 0) return RTS_ERR_INVALID_ARG;
+    if (light && light->type == RTS_LIGHT_POINT && !positions) return RTS_ERR_INVALID_ARG;
+    const float ns = (light && light->nsamples > 1) ? (float)light->nsamples : 1.0f;
+    V3 cd{ k->cameraDirection[0], k->cameraDirection[1], k->cameraDirection[2] };
+    float cl = std::sqrt(dot(cd, cd));
+    if (cl > 0) cd = mul(cd, 1.0f / cl);
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+        V3 n{ normals[i * 4], normals[i * 4 + 1], normals[i * 4 + 2] };
+        uint8_t* o = rgb + i * 3;
+        if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) { o[0] = o[1] = o[2] = 0; continue; }
+        V3 L{ k->lightDirection[0], k->lightDirection[1], k->lightDirection[2] };
+        if (light) {
+            L = V3{ light->xyz[0], light->xyz[1], light->xyz[2] };
+            if (light->type == RTS_LIGHT_POINT) {
+                V3 p{ k->cameraPosition[0] + positions[i * 4], k->cameraPosition[1] + positions[i * 4 + 1],
+                      k->cameraPosition[2] + positions[i * 4 + 2] };
+                L = sub(L, p);
+                float ll = std::sqrt(dot(L, L));
+                if (ll > 0) L = mul(L, 1.0f / ll);
+            }
+        }
+        float ndl = dot(n, L); if (ndl < 0) ndl = 0;
+        float ndv = dot(n, mul(cd, -1.0f)); if (ndv < 0) ndv = 0;
+        float v = 1.25f * ndl * ((float)mask[i] / ns) + 0.15f + 0.05f * (1.0f - ndv);
+        int q = (int)(v * 255.0f + 0.5f); if (q > 255) q = 255; if (q < 0) q = 0;
+        o[0] = o[1] = o[2] = (uint8_t)q;
+    }
     return RTS_OK;
 }

@@ -381,3 +381,34 @@ def test_interleaved_stripes_single_dispatch(ctx):
         ctx.set_option("kernel", -1)
         ctx.free(d_pos)
         ctx.free(d_mask)
+
+
+def test_gbuffer_pass_on_the_gpu_matches_the_host_pass(ctx):
+    """the G-buffer generator on the GPU shares its code with the host version."""
+    wl = workloads.prepare("atrium", 480, 270)
+    pos, nrm, hits = api.primary_gbuffer(wl.packed, wl.scene.eye, wl.scene.target, wl.scene.fovy, wl.W, wl.H)
+    ctx.set_bvh(wl.packed)
+    d_pos = ctx.malloc(pos.nbytes)
+    d_nrm = ctx.malloc(nrm.nbytes)
+    try:
+        api.primary_gbuffer_device(ctx, wl.scene.eye, wl.scene.target, wl.scene.fovy, wl.W, wl.H, d_pos, d_nrm)
+        ctx.synchronize()
+        gpos, gnrm = np.zeros_like(pos), np.zeros_like(nrm)
+        ctx.d2h(gpos, d_pos)
+        ctx.d2h(gnrm, d_nrm)
+        same = (gpos.view(np.uint32) == pos.view(np.uint32)).all(axis=2)
+        assert same.mean() > 0.9999, f"{(~same).sum()} of {same.size} position texels differ"
+        assert np.allclose(gnrm[same], nrm[same], atol=1e-6)
+        # and the shadow mask traced from the device-made G-buffer equals the oracle's on the same buffer
+        d_mask = ctx.malloc(wl.W * wl.H)
+        ctx.trace_shadow_mask_device(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
+        ctx.synchronize()
+        got = np.zeros((wl.H, wl.W), np.uint8)
+        ctx.d2h(got, d_mask)
+        ctx.free(d_mask)
+        want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                        oracle.light_from_product(wl.light, wl.constants), gpos, wl.W, wl.H)
+        assert (got == want).all()
+    finally:
+        ctx.free(d_pos)
+        ctx.free(d_nrm)

@@ -53,3 +53,35 @@ def test_constants_layout():
     arr = k.as_array()
     assert arr.shape == (16,) and arr[0:3].tolist() == [1, 2, 3] and arr[8:11].tolist() == [0, 1, 0]
     assert arr[12] == 640 and arr[13] == 480
+
+
+def test_gbuffer_normals_and_combine(tmp_path):
+    wl = workloads.prepare("cornell", 96, 64, via_obj=False)
+    pos, nrm, hits = api.primary_gbuffer(wl.packed, wl.scene.eye, wl.scene.target, wl.scene.fovy, 96, 64)
+    assert (pos == wl.positions).all()                               # same pass, normals are an extra target
+    hit = pos[..., 3] == 1.0
+    n = nrm[..., :3]
+    assert np.allclose(np.linalg.norm(n[hit], axis=1), 1.0, atol=1e-5) and (n[~hit] == 0).all()
+    view = pos[..., :3][hit]                                          # camera-relative position = view vector
+    assert ((n[hit] * view).sum(1) <= 1e-4).all()                    # normals face the viewer (Model.frag:38)
+    lt = oracle.light_from_product(wl.light, wl.constants)
+    mask, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), lt, wl.positions, 96, 64)
+    rgb = api.combine(wl.constants, wl.light, pos, nrm, mask)
+    assert rgb.shape == (64, 96, 3) and (rgb[~hit] == 0).all() and rgb[hit].min() >= int(0.15 * 255)
+    lit = hit & (mask == 1)
+    dark = hit & (mask == 0)
+    assert rgb[lit].mean() > rgb[dark].mean()                        # Combine.frag: direct light only where lit
+    assert rgb[dark].max() <= int(0.2 * 255 + 1)                     # occluded = ambient only (0.15 .. 0.20)
+    path = api.write_ppm(str(tmp_path / "c.ppm"), rgb)
+    head = open(path, "rb").read(15)
+    assert head.startswith(b"P6\n96 64\n255\n")
+
+
+def test_bvh_blob_round_trip(tmp_path):
+    wl = workloads.prepare("cornell", 8, 8, via_obj=False)
+    path = api.save_bvh(str(tmp_path / "c.bvh"), wl.packed)
+    back = api.load_bvh(path)
+    assert (back == wl.packed).all()
+    open(path, "r+b").write(b"XXXX")
+    with pytest.raises(api.RtsError):
+        api.load_bvh(path)
