@@ -72,6 +72,8 @@ typedef struct rts_light {
     float    offsets[64][4];
 } rts_light;
 
+typedef struct rts_ctx rts_ctx;
+
 /* ---- producer: replaces BVHBuilder::build (Source/BVHBuilder.h:31, BVHBuilder.cpp:248-368;
  *      call site Source/RayTracedShadows.cpp:1031-1037) ---------------------- */
 
@@ -99,11 +101,18 @@ int rts_bvh_build_ex(const float* vertices, uint32_t stride_floats, const uint32
  * count == 5P-2, leaf/inner tags, strictly-forward miss links, tail pointers in range. */
 int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_count_out);
 
+/* BVH build ON THE GPU: Morton order + Karras hierarchy + bottom-up bounds, then the reference's
+ * layout rules (larger-area child first, DFS numbering, miss links, tail; BVHBuilder.cpp:202-244, 308-367).  The tree is
+ * NOT BVHBuilder's SAH tree (use rts_bvh_build for that); it is another valid producer of the same packed layout.
+ * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
+ * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build. */
+int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
+                         const uint32_t* indices, uint32_t prim_count, rts_vec4u* out_packed,
+                         size_t out_capacity_vec4, int install, float* build_ms);
+
 /* ---- consumer: replaces the bind-group + dispatch of
  *      RayTracedShadowsApp::renderShadowMaskCompute (Source/RayTracedShadows.cpp:570-595) and the
  *      BVH upload (Source/RayTracedShadows.cpp:1039-1044) ---------------------- */
-
-typedef struct rts_ctx rts_ctx;
 
 /* One context per device; not thread-safe; owns the device copy of the BVH. */
 int rts_ctx_create(int device_ordinal, rts_ctx** out);

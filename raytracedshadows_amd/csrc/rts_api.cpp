@@ -381,6 +381,19 @@ int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
 }
 const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel.c_str() : ""; }
 
+int rts_ctx_device_ordinal(rts_ctx* c) { return c ? c->device : 0; }
+
+// used by the GPU builder (rts_lbvh.hip): the context takes ownership of a packed stream that is already on the
+// device (finite vertices were checked there; LBVH boxes are min <= max by construction)
+int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t P) {
+    if (!c || !d_packed || count != (size_t)5 * P - 2 || count * 16 >= (1ull << 32)) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
+    c->d_bvh = d_packed;
+    c->bvhVec4 = count; c->P = P; c->bvhFinite = true; c->bvhOrdered = true;
+    return RTS_OK;
+}
+
 // used by the harness (rts_primary.hip): the device copy of the packed stream, NULL before rts_ctx_set_bvh
 const void* rts_ctx_device_bvh(rts_ctx* c) {
     if (!c) return nullptr;

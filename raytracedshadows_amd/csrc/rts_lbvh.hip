@@ -1,0 +1,327 @@
+// BVH build on the GPU: an alternative PRODUCER of the packed node stream of SURVEY.md
+// Appendix A.  Linear BVH: Morton order of the triangle centroids (63-bit codes, hipcub radix sort), Karras'
+// parallel hierarchy, bottom-up bounds, then the reference's own layout rules applied to that topology:
+//   * child with the larger surface area first            (Source/BVHBuilder.cpp:202-208, strict `>` on the right one)
+//   * depth-first (pre-order) numbering, left child = i+1 (cpp:222-238)
+//   * miss link = first index after the subtree, 0xFFFFFFFF at the end (cpp:231-236)
+//   * inner {bboxMin|0xFFFFFFFF}{bboxMax|next}, leaf {v1-v0|2N+prim}{v2-v0|next}, tail v0 per triangle (cpp:308-367)
+// The TREE is not the reference's full-sweep SAH tree (that builder is bvh_builder.cpp, byte-identical to the oracle);
+// any valid stream is a drop-in for the consumer, and masks agree with the SAH stream's up to the slab test's
+// non-conservativeness.
+//
+// Synchronisation: every dependency between nodes crosses a KERNEL BOUNDARY (refit sweeps are repeated launches,
+// numbering walks a finished tree), so nothing relies on in-kernel visibility between CUs / XCDs.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "../../include/rts.h"
+
+extern "C" int rts_ctx_adopt_device_bvh(rts_ctx* ctx, void* d_packed, size_t count_vec4, uint32_t prim_count);  // rts_api.cpp
+extern "C" int rts_ctx_device_ordinal(rts_ctx* ctx);
+
+namespace {
+
+constexpr uint32_t END = 0xFFFFFFFFu;
+
+struct Lbvh {
+    uint32_t P;
+    const float* verts; uint32_t stride; const uint32_t* indices;
+    float* leafLo; float* leafHi;          // 3 floats per triangle (by prim id)
+    uint32_t* sceneBox;                    // 6 order-preserving encoded floats: min xyz, max xyz
+    uint64_t* keys; uint32_t* order;       // Morton key / prim id, sorted position -> prim
+    uint32_t* child;                       // 2 per internal node: node ids (internal i = i, leaf at sorted pos j = P-1+j)
+    uint32_t* parent;                      // per node id
+    float* nodeLo; float* nodeHi;          // 3 floats per internal node
+    uint32_t* leaves;                      // triangles below, per internal node
+    uint32_t* done;                        // per internal node: bounds final
+    uint32_t* pending;                     // [0] = internal nodes not final yet
+    uint32_t* flags;                       // [0] = a non-finite vertex was seen
+};
+
+__device__ __forceinline__ uint32_t encodeOrdered(float f) {          // monotone float -> uint map
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float decodeOrdered(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__global__ void leafBoxesKernel(Lbvh b) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.P) return;
+    float lo[3], hi[3];
+    bool finite = true;
+    for (int c = 0; c < 3; ++c) {
+        const float* v = b.verts + (size_t)b.stride * b.indices[(size_t)p * 3 + c];
+        for (int k = 0; k < 3; ++k) {
+            const float x = v[k];
+            finite = finite && (__builtin_fabsf(x) < __builtin_inff());
+            lo[k] = (c == 0 || x < lo[k]) ? x : lo[k];
+            hi[k] = (c == 0 || hi[k] < x) ? x : hi[k];
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        b.leafLo[(size_t)p * 3 + k] = lo[k];
+        b.leafHi[(size_t)p * 3 + k] = hi[k];
+        const float c = (lo[k] + hi[k]) * 0.5f;                          // centroid as in BVHBuilder (Box3::center)
+        atomicMin(&b.sceneBox[k], encodeOrdered(c));
+        atomicMax(&b.sceneBox[3 + k], encodeOrdered(c));
+    }
+    if (!finite) b.flags[0] = 1;
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {                 // 21 bits -> every third bit
+    uint64_t x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void mortonKernel(Lbvh b) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.P) return;
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float mn = decodeOrdered(b.sceneBox[k]), mx = decodeOrdered(b.sceneBox[3 + k]);
+        const float c = (b.leafLo[(size_t)p * 3 + k] + b.leafHi[(size_t)p * 3 + k]) * 0.5f;
+        const float ext = mx - mn;
+        float t = ext > 0.0f ? (c - mn) / ext : 0.0f;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        uint32_t v = (uint32_t)(t * 2097151.0f);
+        q[k] = v > 2097151u ? 2097151u : v;
+    }
+    b.keys[p] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    b.order[p] = p;
+}
+
+// Karras 2012: length of the common prefix of keys i and j (ties broken by the position, so all keys are distinct)
+__device__ __forceinline__ int commonPrefix(const uint64_t* keys, uint32_t P, int i, int j) {
+    if (j < 0 || j >= (int)P) return -1;
+    const uint64_t a = keys[i], c = keys[j];
+    if (a == c) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ c));
+}
+
+__global__ void hierarchyKernel(Lbvh b, const uint64_t* keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = (int)b.P;
+    if (i >= P - 1) return;
+    const int d = commonPrefix(keys, b.P, i, i + 1) - commonPrefix(keys, b.P, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = commonPrefix(keys, b.P, i, i - d);
+    int lmax = 2;
+    while (commonPrefix(keys, b.P, i, i + lmax * d) > dmin) lmax *= 2;       // bounded: prefix is -1 outside [0,P)
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (commonPrefix(keys, b.P, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = commonPrefix(keys, b.P, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (commonPrefix(keys, b.P, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t left = (lo == gamma) ? (uint32_t)(P - 1 + gamma) : (uint32_t)gamma;
+    const uint32_t right = (hi == gamma + 1) ? (uint32_t)(P - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    b.child[2 * i] = left;
+    b.child[2 * i + 1] = right;
+    b.parent[left] = (uint32_t)i;
+    b.parent[right] = (uint32_t)i;
+    if (i == 0) b.parent[0] = END;
+}
+
+__device__ __forceinline__ float surfaceArea(const float* lo, const float* hi) {   // BVHBuilder.cpp:24-28
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return (ex * ey + ey * ez + ez * ex) * 2.0f;
+}
+
+// One sweep: every internal node whose children were final BEFORE this launch becomes final.
+__global__ void refitSweepKernel(Lbvh b, const uint32_t* order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.P - 1 || b.done[i] == 1) return;
+    uint32_t c[2] = { b.child[2 * i], b.child[2 * i + 1] };
+    float lo[2][3], hi[2][3];
+    uint32_t n[2];
+    for (int k = 0; k < 2; ++k) {
+        if (c[k] >= b.P - 1) {                                   // leaf at sorted position c-(P-1)
+            const uint32_t prim = order[c[k] - (b.P - 1)];
+            for (int a = 0; a < 3; ++a) { lo[k][a] = b.leafLo[(size_t)prim * 3 + a]; hi[k][a] = b.leafHi[(size_t)prim * 3 + a]; }
+            n[k] = 1;
+        } else {
+            if (b.done[c[k]] != 1) return;                       // not yet: a later sweep
+            for (int a = 0; a < 3; ++a) { lo[k][a] = b.nodeLo[(size_t)c[k] * 3 + a]; hi[k][a] = b.nodeHi[(size_t)c[k] * 3 + a]; }
+            n[k] = b.leaves[c[k]];
+        }
+    }
+    if (surfaceArea(lo[1], hi[1]) > surfaceArea(lo[0], hi[0])) {  // larger child first (cpp:202-208)
+        b.child[2 * i] = c[1];
+        b.child[2 * i + 1] = c[0];
+    }
+    for (int a = 0; a < 3; ++a) {
+        b.nodeLo[(size_t)i * 3 + a] = lo[0][a] < lo[1][a] ? lo[0][a] : lo[1][a];
+        b.nodeHi[(size_t)i * 3 + a] = hi[0][a] > hi[1][a] ? hi[0][a] : hi[1][a];
+    }
+    b.leaves[i] = n[0] + n[1];
+    b.done[i] = 2;                                               // final, becomes visible as 1 after this launch
+    atomicSub(&b.pending[0], 1u);
+}
+__global__ void refitCommitKernel(Lbvh b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.P - 1 && b.done[i] == 2) b.done[i] = 1;
+}
+
+// Pre-order index of a node = sum over its ancestors of (1 + size of the sibling subtree visited before it).
+__global__ void emitKernel(Lbvh b, const uint32_t* order, uint32_t* packed) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t P = b.P, N = 2 * P - 1;
+    if (id >= N) return;
+    const bool leaf = id >= P - 1;
+    const uint32_t size = leaf ? 1u : 2u * b.leaves[id] - 1u;
+    uint32_t index = 0, cur = id;
+    for (uint32_t guard = 0; guard < 4096 && b.parent[cur] != END; ++guard) {
+        const uint32_t par = b.parent[cur];
+        index += 1;
+        if (b.child[2 * par + 1] == cur) {                       // second child: the first one's subtree comes before
+            const uint32_t first = b.child[2 * par];
+            index += first >= P - 1 ? 1u : 2u * b.leaves[first] - 1u;
+        }
+        cur = par;
+    }
+    const uint32_t next = index + size >= N ? END : index + size;
+    uint32_t* o = packed + (size_t)index * 8;
+    if (leaf) {
+        const uint32_t prim = order[id - (P - 1)];
+        const float* v0 = b.verts + (size_t)b.stride * b.indices[(size_t)prim * 3 + 0];
+        const float* v1 = b.verts + (size_t)b.stride * b.indices[(size_t)prim * 3 + 1];
+        const float* v2 = b.verts + (size_t)b.stride * b.indices[(size_t)prim * 3 + 2];
+        o[0] = __float_as_uint(v1[0] - v0[0]); o[1] = __float_as_uint(v1[1] - v0[1]); o[2] = __float_as_uint(v1[2] - v0[2]);
+        o[3] = 2 * N + prim;
+        o[4] = __float_as_uint(v2[0] - v0[0]); o[5] = __float_as_uint(v2[1] - v0[1]); o[6] = __float_as_uint(v2[2] - v0[2]);
+        o[7] = next;
+        uint32_t* t = packed + ((size_t)2 * N + prim) * 4;
+        t[0] = __float_as_uint(v0[0]); t[1] = __float_as_uint(v0[1]); t[2] = __float_as_uint(v0[2]); t[3] = 0;
+    } else {
+        for (int a = 0; a < 3; ++a) { o[a] = __float_as_uint(b.nodeLo[(size_t)id * 3 + a]); o[4 + a] = __float_as_uint(b.nodeHi[(size_t)id * 3 + a]); }
+        o[3] = END;
+        o[7] = next;
+    }
+}
+
+__global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P == 1: the root is the leaf
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float* v0 = b.verts + (size_t)b.stride * b.indices[0];
+    const float* v1 = b.verts + (size_t)b.stride * b.indices[1];
+    const float* v2 = b.verts + (size_t)b.stride * b.indices[2];
+    packed[0] = __float_as_uint(v1[0] - v0[0]); packed[1] = __float_as_uint(v1[1] - v0[1]); packed[2] = __float_as_uint(v1[2] - v0[2]);
+    packed[3] = 2;
+    packed[4] = __float_as_uint(v2[0] - v0[0]); packed[5] = __float_as_uint(v2[1] - v0[1]); packed[6] = __float_as_uint(v2[2] - v0[2]);
+    packed[7] = END;
+    packed[8] = __float_as_uint(v0[0]); packed[9] = __float_as_uint(v0[1]); packed[10] = __float_as_uint(v0[2]); packed[11] = 0;
+}
+
+struct DeviceArena {            // frees everything it handed out, whatever path leaves the function
+    void* ptrs[24]; int n = 0;
+    template <typename T> hipError_t get(T** p, size_t bytes) {
+        void* v = nullptr;
+        hipError_t e = hipMalloc(&v, bytes ? bytes : 16);
+        if (e == hipSuccess) { ptrs[n++] = v; *p = (T*)v; }
+        return e;
+    }
+    void release(void* keep = nullptr) { for (int i = 0; i < n; ++i) if (ptrs[i] != keep) (void)hipFree(ptrs[i]); n = 0; }
+};
+
+#define LB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { arena.release(); return RTS_ERR_HIP + (int)e_; } } while (0)
+
+} // namespace
+
+extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
+                                    const uint32_t* indices, uint32_t P, rts_vec4u* out_packed, size_t out_cap,
+                                    int install, float* build_ms) {
+    if (!ctx || !vertices || !indices || P == 0 || stride < 3 || P > 0x0CCCCCCCu) return RTS_ERR_INVALID_ARG;
+    const size_t count = (size_t)5 * P - 2;
+    if (out_packed && out_cap < count) return RTS_ERR_CAPACITY;
+    for (size_t i = 0; i < (size_t)3 * P; ++i)
+        if ((size_t)indices[i] * stride + 3 > vertex_floats) return RTS_ERR_INVALID_ARG;
+    hipError_t e0 = hipSetDevice(rts_ctx_device_ordinal(ctx));
+    if (e0 != hipSuccess) return RTS_ERR_HIP + (int)e0;
+
+    DeviceArena arena;
+    Lbvh b{};
+    b.P = P; b.stride = stride;
+    float* d_verts; uint32_t* d_idx; uint32_t* d_packed;
+    uint64_t* keysAlt; uint32_t* orderAlt;
+    LB_HIP(arena.get(&d_verts, vertex_floats * 4));
+    LB_HIP(arena.get(&d_idx, (size_t)P * 12));
+    LB_HIP(arena.get(&d_packed, count * 16 + 64));
+    LB_HIP(arena.get(&b.leafLo, (size_t)P * 12)); LB_HIP(arena.get(&b.leafHi, (size_t)P * 12));
+    LB_HIP(arena.get(&b.sceneBox, 32));
+    LB_HIP(arena.get(&b.keys, (size_t)P * 8)); LB_HIP(arena.get(&keysAlt, (size_t)P * 8));
+    LB_HIP(arena.get(&b.order, (size_t)P * 4)); LB_HIP(arena.get(&orderAlt, (size_t)P * 4));
+    LB_HIP(arena.get(&b.child, (size_t)P * 8)); LB_HIP(arena.get(&b.parent, (size_t)P * 8));
+    LB_HIP(arena.get(&b.nodeLo, (size_t)P * 12)); LB_HIP(arena.get(&b.nodeHi, (size_t)P * 12));
+    LB_HIP(arena.get(&b.leaves, (size_t)P * 4)); LB_HIP(arena.get(&b.done, (size_t)P * 4));
+    LB_HIP(arena.get(&b.pending, 16)); LB_HIP(arena.get(&b.flags, 16));
+    b.verts = d_verts; b.indices = d_idx;
+
+    LB_HIP(hipMemcpy(d_verts, vertices, vertex_floats * 4, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(d_idx, indices, (size_t)P * 12, hipMemcpyHostToDevice));
+    hipEvent_t ev0, ev1;
+    LB_HIP(hipEventCreate(&ev0)); LB_HIP(hipEventCreate(&ev1));
+    LB_HIP(hipEventRecord(ev0, nullptr));
+
+    const uint32_t boxInit[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0 };
+    LB_HIP(hipMemcpy(b.sceneBox, boxInit, 32, hipMemcpyHostToDevice));
+    LB_HIP(hipMemset(b.flags, 0, 16));
+    LB_HIP(hipMemset(b.done, 0, (size_t)P * 4));
+    const uint32_t pend = P - 1;
+    LB_HIP(hipMemcpy(b.pending, &pend, 4, hipMemcpyHostToDevice));
+    const dim3 block(256), gridP((P + 255) / 256), gridN((2 * P - 1 + 255) / 256);
+    hipLaunchKernelGGL(leafBoxesKernel, gridP, block, 0, nullptr, b);
+    uint32_t flag = 0;
+    LB_HIP(hipMemcpy(&flag, b.flags, 4, hipMemcpyDeviceToHost));
+    if (flag) { arena.release(); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return RTS_ERR_NONFINITE; }
+
+    const uint64_t* sortedKeys = b.keys;
+    const uint32_t* sortedOrder = b.order;
+    if (P > 1) {
+        hipLaunchKernelGGL(mortonKernel, gridP, block, 0, nullptr, b);
+        size_t tempBytes = 0;
+        LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, b.keys, keysAlt, b.order, orderAlt, (int)P, 0, 63, nullptr));
+        void* temp;
+        LB_HIP(arena.get(&temp, tempBytes));
+        LB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, b.keys, keysAlt, b.order, orderAlt, (int)P, 0, 63, nullptr));
+        sortedKeys = keysAlt; sortedOrder = orderAlt;
+        hipLaunchKernelGGL(hierarchyKernel, gridP, block, 0, nullptr, b, sortedKeys);
+        // bottom-up bounds: repeated sweeps, each finalising the nodes whose children were final before it
+        uint32_t left = pend;
+        for (int sweep = 0; sweep < 4096 && left != 0; ++sweep) {
+            hipLaunchKernelGGL(refitSweepKernel, gridP, block, 0, nullptr, b, sortedOrder);
+            hipLaunchKernelGGL(refitCommitKernel, gridP, block, 0, nullptr, b);
+            if ((sweep & 7) == 7 || sweep < 2) LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
+        }
+        LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
+        if (left != 0) { arena.release(); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return RTS_ERR_BAD_BVH; }
+        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, sortedOrder, (uint32_t*)d_packed);
+    } else {
+        hipLaunchKernelGGL(emitSingleKernel, dim3(1), dim3(64), 0, nullptr, b, (uint32_t*)d_packed);
+    }
+    LB_HIP(hipEventRecord(ev1, nullptr));
+    LB_HIP(hipEventSynchronize(ev1));
+    LB_HIP(hipGetLastError());
+    float ms = 0;
+    LB_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    if (build_ms) *build_ms = ms;
+    if (out_packed) LB_HIP(hipMemcpy(out_packed, d_packed, count * 16, hipMemcpyDeviceToHost));
+    if (install) {
+        int s = rts_ctx_adopt_device_bvh(ctx, d_packed, count, P);   // the context owns d_packed from here on
+        arena.release(s == RTS_OK ? (void*)d_packed : nullptr);
+        return s;
+    }
+    arena.release();
+    return RTS_OK;
+}
