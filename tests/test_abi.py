@@ -44,3 +44,18 @@ def test_product_never_links_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "librts_oracle" not in text and "import oracle" not in text, f
+
+
+def test_missing_library_fails_loudly_but_build_helper_still_imports():
+    """The product path has no fallback: without librts.so the API import raises; the build helper does not need it."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RTS_LIB="/nonexistent/librts.so", PYTHONPATH=ROOT)
+    ok = subprocess.run([sys.executable, "-c", "import raytracedshadows_amd.build, raytracedshadows_amd"], env=env,
+                        capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    bad = subprocess.run([sys.executable, "-c", "import raytracedshadows_amd.api"], env=env, capture_output=True, text=True)
+    assert bad.returncode != 0 and "no CPU fallback" in bad.stderr
+    bad = subprocess.run([sys.executable, "-c", "import raytracedshadows_amd as r; r.ShadowContext"], env=env,
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "is missing" in bad.stderr
