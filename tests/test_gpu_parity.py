@@ -412,3 +412,50 @@ def test_gbuffer_pass_on_the_gpu_matches_the_host_pass(ctx):
     finally:
         ctx.free(d_pos)
         ctx.free(d_nrm)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_scenes_cameras_and_options(ctx, seed):
+    """Property test: whatever the scene, camera, light, frame size, sample count and tuning knobs, every kernel's
+    mask equals the oracle's.  Exercises mixed sign patterns, sparse tiles, early-dying packets and dissolving."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([1, 2, 5, 40, 300, 3000]))
+    kind = seed % 3
+    if kind == 0:                                                     # random soup
+        c = rs.random_sample((n, 1, 3)) * 20 - 10
+        verts = (c + (rs.random_sample((n, 3, 3)) - 0.5) * rs.choice([0.2, 2.0, 8.0])).astype(np.float32).reshape(-1, 3)
+    elif kind == 1:                                                   # many coplanar, axis-aligned, touching triangles
+        g = rs.randint(0, 6, size=(n, 1, 3)).astype(np.float32)
+        verts = (g + rs.randint(0, 2, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    else:                                                             # huge coordinates + tiny triangles
+        c = (rs.random_sample((n, 1, 3)) - 0.5) * 2e4
+        verts = (c + (rs.random_sample((n, 3, 3)) - 0.5) * 1e-2).astype(np.float32).reshape(-1, 3)
+    idx = np.arange(verts.shape[0], dtype=np.uint32)
+    packed = api.BVHBuilder().build(verts, 3, idx, n).m_packedNodes
+    lo, hi = verts.min(0), verts.max(0)
+    W, H = int(rs.randint(1, 300)), int(rs.randint(1, 200))
+    eye = (hi + (hi - lo) * rs.random_sample(3) + 1).astype(np.float32)
+    target = (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32)
+    pos, _ = api.primary_positions(packed, eye, target, 1.0, W, H)
+    k = api.RayTracingConstants.make(eye, [0.3, 0.8, 0.5], W, H)
+    lights = [None,
+              api.Light.make(api.Light.POINT, (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32)),   # inside the scene
+              api.Light.make(api.Light.DIRECTIONAL, [0, 1, 0]),                                                # axis-parallel: EXACT path
+              api.Light.make(api.Light.POINT, hi + 5, scenes.jitter_offsets(int(rs.randint(2, 9)), 0.7, seed))]
+    ctx.set_bvh(packed)
+    try:
+        for light in lights:
+            want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(light, k), pos, W, H)
+            for kernel in range(ctx.get_option("kernel_count")):
+                ctx.set_option("kernel", kernel)
+                ctx.set_option("packet_budget", int(rs.choice([1, 2, 8, 50])))
+                ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
+                ctx.set_option("block_waves", int(rs.choice([1, 4])))
+                got = ctx.trace_shadow_mask(k, pos, W, H, light=light)
+                bad = int((got != want).sum())
+                assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
+    finally:
+        ctx.set_option("kernel", -1)
+        ctx.set_option("packet_budget", 8)
+        ctx.set_option("packet_share", 4)
+        ctx.set_option("block_waves", 1)
