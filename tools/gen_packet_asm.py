@@ -78,7 +78,8 @@ def loop(K, form):
     for k in range(K):
         r = f"s[{54 + 2 * k}:{55 + 2 * k}]"
         L += [f"s_andn2_b64 s[50:51], %[m{k}], {r}",   # members whose own test failed: they leave the packet ...
-              f"s_cbranch_scc0 1{k}f",
+              # (K == 1: nobody leaves => the membership is unchanged and non-empty: straight to the next node)
+              "s_cbranch_scc0 5b" if K == 1 else f"s_cbranch_scc0 1{k}f",
               "s_mov_b64 s[48:49], exec",
               "s_mov_b64 exec, s[50:51]",
               f"v_mov_b32 %[w{k}], s47",                # ... and wait on the miss link
