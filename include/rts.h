@@ -169,6 +169,9 @@ int rts_timer_end(rts_ctx* ctx, void* stream);
 int rts_timer_elapsed_ms(rts_ctx* ctx, float* ms);
 /* Name of the kernel the last trace launched (for matching rocprofv3 rows). */
 const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
+/* Dispatch order of the image tiles for traces whose workgroup count equals `count`: workgroup i works on tile
+ * order[i] (a permutation of 0..count-1; NULL or 0 restores the natural order).  Speed only. */
+int rts_ctx_set_tile_order(rts_ctx* ctx, const uint32_t* order, size_t count);
 /* Diagnostics (tools/wave_stats.py): after rts_ctx_set_option(ctx, "wave_stats", n_waves) the packet
  * kernels record {start clock, end clock, side-steps left, block xy} per wave; this copies them out. */
 int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);

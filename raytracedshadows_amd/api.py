@@ -137,6 +137,7 @@ _sig("rts_timer_begin", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_timer_end", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_timer_elapsed_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
+_sig("rts_ctx_set_tile_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
      C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
@@ -330,6 +331,13 @@ class ShadowContext:
 
     def last_kernel_name(self):
         return _lib.rts_ctx_last_kernel_name(self._h).decode()
+
+    def set_tile_order(self, order):
+        if order is None:
+            _check(_lib.rts_ctx_set_tile_order(self._h, None, 0), "rts_ctx_set_tile_order")
+            return
+        order = np.ascontiguousarray(order, np.uint32)
+        _check(_lib.rts_ctx_set_tile_order(self._h, _ptr(order), order.size), "rts_ctx_set_tile_order")
 
     def read_wave_stats(self, waves):
         out = np.zeros((waves, 4), dtype=np.uint64)

@@ -29,6 +29,7 @@ struct rts_ctx {
     int packetBudget = 8;
     int packetShare = 4;
     int blockWaves = 1;
+    uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
 };
@@ -146,6 +147,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_waveStats) (void)hipFree(c->d_waveStats);
+    if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -244,6 +246,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.swizzle = c->swizzle ? 1u : 0u;
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
     if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) p.waveStats = c->d_waveStats;
+    if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;
@@ -399,6 +402,21 @@ const void* rts_ctx_device_bvh(rts_ctx* c) {
     if (!c) return nullptr;
     (void)hipSetDevice(c->device);
     return c->d_bvh;
+}
+
+// Dispatch order for the next traces whose block count equals `count` (NULL/0 = natural order).  Every tile index
+// must appear exactly once (checked).  Speed only: results never depend on it.
+int rts_ctx_set_tile_order(rts_ctx* c, const uint32_t* order, size_t count) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    if (c->d_tileOrder) { RTS_HIP(hipFree(c->d_tileOrder)); c->d_tileOrder = nullptr; c->tileOrderCount = 0; }
+    if (!order || count == 0) return RTS_OK;
+    std::string seen(count, 0);
+    for (size_t i = 0; i < count; ++i) { if (order[i] >= count || seen[order[i]]) return RTS_ERR_INVALID_ARG; seen[order[i]] = 1; }
+    RTS_HIP(hipMalloc((void**)&c->d_tileOrder, count * 4));
+    RTS_HIP(hipMemcpy(c->d_tileOrder, order, count * 4, hipMemcpyHostToDevice));
+    c->tileOrderCount = count;
+    return RTS_OK;
 }
 
 int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {

@@ -13,6 +13,7 @@ enum Variant {
     V_PACKET2 = 4,     // same, 2 rays per lane (16x8 px per wave)
     V_PACKET4 = 5,     // same, 4 rays per lane (16x16 px per wave)
     V_PACKET_PF = 6,   // V_PACKET with the sequential successor node prefetched into a second SGPR set
+    V_SHARE = 7,       // lane-per-ray with work sharing inside the wave (idle lanes take half of a busy ray's range)
     V_COUNT,
     V_AUTO = -1        // packet for big launches, straight for small ones
 };
@@ -36,6 +37,7 @@ struct TraceParams {
     const void* rays;         // rts_ray[n] (device)
     uint8_t* out;
     uint64_t nrays;
+    const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive

@@ -153,6 +153,98 @@ __device__ __forceinline__ bool traverseStraight(const NodeStream& bvh, const Ra
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// V_SHARE: lane-per-ray walk with WORK SHARING inside the wave (used for dissolved packets too).
+//
+// A stackless walk that stands on node c and may go up to `bound` visits, in index order, subtree(c)
+// and then everything from next(c) on.  The two parts are independent: any lane can walk
+// [next(c), bound) for the same ray while the original lane keeps [c, next(c)) -- and since any-hit is an
+// OR over the tests, the pieces can run in parallel on different lanes.  Whenever at least SHARE_MIN_IDLE
+// lanes have nothing to do, the k-th idle lane takes the second part of the k-th busy lane's range (ray
+// copied with ds_bpermute, lane numbers exchanged through 256 B of LDS).  A piece that finds a hit marks
+// its owner in a wave-uniform mask; pieces of an occluded owner stop.  The set of tests per ray is a
+// superset of the shader's up to its first hit, so the mask is unchanged; the long tail of a wave whose
+// rays scatter (atrium: one ray visiting 381 nodes at L2 latency) is spread over all 64 lanes.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t SHARE_MIN_IDLE = 8;
+
+template <bool FAST>
+__device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t node = live ? start : END, bound = END, owner = lane;
+    uint64_t occludedOwners = 0;                       // wave-uniform
+    uint32_t iter = 0;
+    for (;;) {
+        // pieces of an owner that is already known to be occluded have nothing left to prove
+        if ((occludedOwners >> owner) & 1ull) node = END;
+        const bool active = node < bound;
+        const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+        if (act == 0) break;
+        u32x4 a{ 0, 0, 0, END }, b{ 0, 0, 0, END };
+        if (active) { a = bvh.vec4(node * 2); b = bvh.vec4(node * 2 + 1); }
+        if ((iter++ & 3u) == 0) {
+            const uint64_t idle = ~act;
+            const bool canGive = active && b.w < bound;              // there is a second part to give away
+            const uint64_t givers = __builtin_amdgcn_ballot_w64(canGive);
+            const uint32_t nIdle = (uint32_t)__builtin_popcountll(idle), nGive = (uint32_t)__builtin_popcountll(givers);
+            if (nIdle >= SHARE_MIN_IDLE && nGive != 0) {
+                const uint32_t pairs = nIdle < nGive ? nIdle : nGive;
+                const uint32_t below = (1u << (lane & 31u)) - 1u;
+                const uint32_t rankG = lane < 32 ? __builtin_popcount((uint32_t)givers & below)
+                                                 : __builtin_popcount((uint32_t)givers) + __builtin_popcount((uint32_t)(givers >> 32) & below);
+                const uint32_t rankI = lane < 32 ? __builtin_popcount((uint32_t)idle & below)
+                                                 : __builtin_popcount((uint32_t)idle) + __builtin_popcount((uint32_t)(idle >> 32) & below);
+                const bool gives = canGive && rankG < pairs;
+                const bool takes = !active && rankI < pairs;
+                if (gives) ldsSlots[rankG] = lane;                   // k-th giver announces itself ...
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t src = takes ? ldsSlots[rankI] : lane;  // ... to the k-th idle lane
+                // the taker copies the ray and the second part of the range (every lane reads its `src`, givers read themselves)
+                const int sel = (int)(src << 2);
+                const float ox = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.o.x)));
+                const float oy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.o.y)));
+                const float oz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.o.z)));
+                const float dx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.d.x)));
+                const float dy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.d.y)));
+                const float dz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.d.z)));
+                const float ix = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.inv.x)));
+                const float iy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.inv.y)));
+                const float iz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.inv.z)));
+                const float tm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.tmax)));
+                const uint32_t srcNext = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)b.w);
+                const uint32_t srcBound = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)bound);
+                const uint32_t srcOwner = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)owner);
+                if (takes) {
+                    r.o = F3{ ox, oy, oz }; r.d = F3{ dx, dy, dz }; r.inv = F3{ ix, iy, iz }; r.tmax = tm;
+                    node = srcNext; bound = srcBound; owner = srcOwner;   // starts walking next iteration
+                }
+                if (gives) bound = b.w;                              // keeps [node, next(node))
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        bool hitNow = false;
+        if (active) {
+            if (a.w != END) {
+                u32x4 t = bvh.vec4(a.w);
+                hitNow = triHit(r, xyz(t), xyz(a), xyz(b));
+                node = hitNow ? END : b.w;
+            } else {
+                const bool h = boxHit<FAST>(r, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z),
+                                            __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                node = h ? node + 1 : b.w;
+            }
+        }
+        uint64_t hits = __builtin_amdgcn_ballot_w64(hitNow);
+        while (hits) {                                               // rare: record the owners that just got occluded
+            const int l = __builtin_ctzll(hits);
+            occludedOwners |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)owner, l);
+            hits &= hits - 1;
+        }
+    }
+    return (occludedOwners >> lane) & 1ull;
+}
+
 // V_WHILEWHILE: descend inner nodes until every lane of the wave holds a leaf (or is done), then
 // run the triangle test once for all of them.  Same set of tests per ray as the shader.
 template <bool FAST>
@@ -285,7 +377,8 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 
 template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
-                                               const bool (&live)[K], bool (&result)[K], int32_t* sideStepsLeft = nullptr) {
+                                               const bool (&live)[K], bool (&result)[K], uint32_t* lds,
+                                               int32_t* sideStepsLeft = nullptr) {
     const ConstNodePtr nodes = (ConstNodePtr)(uintptr_t)p.bvh;
     const ConstVec4Ptr vec4s = (ConstVec4Ptr)(uintptr_t)p.bvh;
     uint64_t members[K], occluded[K];
@@ -303,7 +396,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     if (any == 0) return;
     if (!p.bvhFinite || unsafe != 0) {       // a NaN could occur somewhere in this wave: EXACT form, lane per ray
 #pragma unroll
-        for (int k = 0; k < K; ++k) result[k] = traverseStraight<false>(bvh, r[k], live[k]);
+        for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], 0u, lds);
         return;
     }
     // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test
@@ -389,14 +482,15 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
-            const bool h = traverseStraight<true>(bvh, r[k], mine != END, mine);
+            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds);
             result[k] = result[k] || h;
         }
     }
 }
 
 template <int VARIANT, bool FAST>
-__device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live) {
+__device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t* lds) {
+    if (VARIANT == V_SHARE) return traverseShare<FAST>(bvh, r, live, 0u, lds);
     if (VARIANT == V_WHILEWHILE) return traverseWhileWhile<FAST>(bvh, r, live);
     if (VARIANT == V_POSTPONE) return traversePostpone<FAST>(bvh, r, live);
     return traverseStraight<FAST>(bvh, r, live);
@@ -410,6 +504,13 @@ __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream&
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool blockToXY(const TraceParams& p, uint32_t bid, uint32_t* bx, uint32_t* by) {
     uint32_t b = bid;
+    if (p.tileOrder) {                           // dispatch order given by the caller (longest tiles first)
+        if (b >= p.nBlocks) return false;
+        b = p.tileOrder[b];
+        *by = b / p.blocksX;
+        *bx = b - *by * p.blocksX;
+        return true;
+    }
     if (p.swizzle) {
         uint32_t per = p.gridBlocks / 8u;           // gridBlocks is padded to a multiple of 8
         b = (bid % 8u) * per + bid / 8u;
@@ -442,6 +543,8 @@ __device__ __forceinline__ uint32_t ownedRow(const TraceParams& p, uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 template <int VARIANT>
 __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
+    __shared__ uint32_t shareSlots[4][64];       // lane numbers exchanged by traverseShare (256 B per wave)
+    uint32_t* lds = shareSlots[threadIdx.x >> 6];
     uint32_t bx, by;
     if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -463,9 +566,9 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
         bool unsafe = live && !raySafe(r);
         bool occluded;
         if (p.bvhFinite && __builtin_amdgcn_ballot_w64(unsafe) == 0)
-            occluded = traverse<VARIANT, true>(p, bvh, r, live);
+            occluded = traverse<VARIANT, true>(p, bvh, r, live, lds);
         else
-            occluded = traverse<VARIANT, false>(p, bvh, r, live);
+            occluded = traverse<VARIANT, false>(p, bvh, r, live, lds);
         lit += occluded ? 0u : 1u;                                  // comp:148
     }
     if (live) __builtin_nontemporal_store((uint8_t)lit, &p.mask[pix]);   // comp:150
@@ -477,6 +580,8 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // frees its slot without waiting for three siblings).
 template <int K, int WPB, bool PREFETCH = false>
 __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p) {
+    __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
+    uint32_t* lds = shareSlots[threadIdx.x >> 6];
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx, by;
     if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
@@ -509,7 +614,7 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
         bool occluded[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
-        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, &left);
+        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -529,6 +634,8 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
+    __shared__ uint32_t shareSlots[4][64];
+    uint32_t* lds = shareSlots[threadIdx.x >> 6];
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool live = i < p.nrays;
     Ray r;
@@ -541,18 +648,18 @@ __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     r.inv = F3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };
     const NodeStream bvh = openStream(p);
     bool occluded;
-    if (VARIANT >= V_PACKET) {                   // 64 consecutive rays as one packet (falls apart if incoherent)
+    if (VARIANT >= V_PACKET && VARIANT != V_SHARE) {   // 64 consecutive rays as one packet (falls apart if incoherent)
         const Ray rr[1] = { r };
         const bool ll[1] = { live };
         bool oo[1];
-        traversePacket<1>(p, bvh, rr, ll, oo);
+        traversePacket<1>(p, bvh, rr, ll, oo, lds);
         occluded = oo[0];
     } else {
         bool unsafe = live && !raySafe(r);
         if (p.bvhFinite && __builtin_amdgcn_ballot_w64(unsafe) == 0)
-            occluded = traverse<VARIANT, true>(p, bvh, r, live);
+            occluded = traverse<VARIANT, true>(p, bvh, r, live, lds);
         else
-            occluded = traverse<VARIANT, false>(p, bvh, r, live);
+            occluded = traverse<VARIANT, false>(p, bvh, r, live, lds);
     }
     if (live) p.out[i] = occluded ? 0 : 1;
 }
@@ -569,19 +676,21 @@ const char* kernelName(int variant, bool mask) {
     case V_PACKET2: return mask ? "shadowMaskPacketKernel<2>" : "traceRaysKernel<3>";
     case V_PACKET4: return mask ? "shadowMaskPacketKernel<4>" : "traceRaysKernel<3>";
     case V_PACKET_PF: return mask ? "shadowMaskPacketKernel<1,pf>" : "traceRaysKernel<3>";
+    case V_SHARE: return mask ? "shadowMaskKernel<7>" : "traceRaysKernel<7>";
     }
     return "?";
 }
 
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH) {
-    const uint32_t f = (variant >= V_PACKET && wavesPerBlock == 1) ? 1u : 2u;   // block = f x f wave tiles
+    const bool packet = variant >= V_PACKET && variant <= V_PACKET_PF;
+    const uint32_t f = (packet && wavesPerBlock == 1) ? 1u : 2u;                // block = f x f wave tiles
     *blockW = f * ((variant == V_PACKET2 || variant == V_PACKET4) ? 16u : 8u);
     *blockH = f * (variant == V_PACKET4 ? 16u : 8u);
 }
 
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream) {
     dim3 grid(p.gridBlocks), block(256);
-    if (variant >= V_PACKET && wavesPerBlock == 1) {
+    if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
         case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, 0, stream, p); break;
@@ -596,6 +705,7 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     case V_STRAIGHT: hipLaunchKernelGGL(shadowMaskKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(shadowMaskKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(shadowMaskKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
+    case V_SHARE: hipLaunchKernelGGL(shadowMaskKernel<V_SHARE>, grid, block, 0, stream, p); break;
     case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4>), grid, block, 0, stream, p); break;
     case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4>), grid, block, 0, stream, p); break;
     case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4>), grid, block, 0, stream, p); break;
@@ -611,6 +721,7 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
     case V_STRAIGHT: hipLaunchKernelGGL(traceRaysKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(traceRaysKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(traceRaysKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
+    case V_SHARE: hipLaunchKernelGGL(traceRaysKernel<V_SHARE>, grid, block, 0, stream, p); break;
     case V_PACKET: case V_PACKET2: case V_PACKET4: case V_PACKET_PF:
         hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
