@@ -89,12 +89,28 @@ def main():
     host_threads = max(1, (os.cpu_count() or 1) // max(1, N))
 
     # ---- inputs (untimed): scene -> OBJ -> BVH -> camera -> G-buffer positions -------------------
+    # N > 1: the BVH is built ONCE (rank 0) and broadcast as the packed Appendix-A stream (control plane, gloo);
+    # every rank uploads it to its own GPU and renders its own G-buffer through it.
     scene = scenes.SCENES[scene_name]()
     if args.scaling == "weak" and N > 1:
         # frame `rank` of a camera path: each GPU renders a different frame of the same scene
         step = (scene.target - scene.eye) * np.float32(0.01 * rank)
         scene.eye = (scene.eye + step).astype(np.float32)
-    wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say)
+    shared_packed = None
+    if dist:
+        import torch
+        count = int(api.packed_count(scene.triangle_count))
+        buf = torch.zeros((count, 4), dtype=torch.int32)
+        if rank == 0:
+            verts, idx = scene.flat()
+            t0 = time.time()
+            built = api.BVHBuilder().build(verts, 8, idx, scene.triangle_count).m_packedNodes
+            say(f"rank 0 built the BVH in {time.time() - t0:.2f}s; broadcasting {built.nbytes / 1e6:.0f} MB")
+            buf.copy_(torch.from_numpy(built.view(np.int32)))
+        dist.broadcast(buf, src=0)
+        shared_packed = buf.numpy().view(np.uint32)
+    wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say,
+                           via_obj=not dist, packed=shared_packed)
     rays_per_frame = wl.rays
 
     BAND = 32

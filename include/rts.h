@@ -119,11 +119,20 @@ int rts_ctx_create(int device_ordinal, rts_ctx** out);
 int rts_ctx_destroy(rts_ctx* ctx);
 
 /* == Gfx_CreateBuffer(Storage, stride 16, count, m_packedNodes.data()) (cpp:1039-1044).
- * Validates, copies H2D once and derives the device-private traversal layout. */
+ * Validates (structure, finiteness, box ordering) and copies H2D once; the device copy is the same Appendix-A bytes. */
 int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
 
-/* Tuning knobs ("kernel" = variant id, "treelet_nodes", "xcd_swizzle", ...).  Unknown key ->
- * RTS_ERR_INVALID_ARG.  Results never depend on any option. */
+/* Tuning knobs.  Results never depend on any of them (tests/test_gpu_parity.py).  Unknown key or bad value ->
+ * RTS_ERR_INVALID_ARG.
+ *   "kernel"        -1 = auto (default: packet kernel for >= 256 K pixels, lane-per-ray below); 0 straight,
+ *                   1 while-while, 2 postpone, 3 packet (8x8 px / wave), 4 packet2 (16x8), 5 packet4 (16x16),
+ *                   6 packet + successor prefetch, 7 lane-per-ray with work sharing.  get "kernel_count" = 8.
+ *   "packet_budget" side-steps between two coherence checks of a packet (default 8)
+ *   "packet_share"  a packet dissolves when it picks up fewer than share/16 of its live rays per side-step (default 4)
+ *   "block_waves"   waves per workgroup of the packet kernels: 1 (default) or 4
+ *   "xcd_swizzle"   1 = contiguous image chunk per XCD (default 0: measured slower)
+ *   "wave_stats"    diagnostics, see rts_ctx_read_wave_stats
+ *   get only: "bvh_finite", "bvh_ordered" (which slab-test forms the uploaded stream allows) */
 int rts_ctx_set_option(rts_ctx* ctx, const char* key, int value);
 int rts_ctx_get_option(rts_ctx* ctx, const char* key, int* value);
 

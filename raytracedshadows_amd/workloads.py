@@ -25,7 +25,7 @@ class Workload:
     pass
 
 
-def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None):
+def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None, packed=None):
     say = log or (lambda *a: None)
     wl = Workload()
     t0 = time.time()
@@ -42,19 +42,25 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
         verts, indices = sc.flat()
     prim_count = verts.shape[0] // 3
     t0 = time.time()
-    builder = api.BVHBuilder(threads=threads).build(verts, 8, indices, prim_count)
-    wl.build_seconds = time.time() - t0
-    say(f"BVH built in {wl.build_seconds:.2f}s ({builder.m_packedNodes.nbytes / 1e6:.1f} MB packed)")
+    if packed is None:
+        builder = api.BVHBuilder(threads=threads).build(verts, 8, indices, prim_count)
+        packed_nodes, nodes = builder.m_packedNodes, builder.m_nodes
+        wl.build_seconds = time.time() - t0
+        say(f"BVH built in {wl.build_seconds:.2f}s ({packed_nodes.nbytes / 1e6:.1f} MB packed)")
+    else:                                        # a stream built elsewhere (e.g. broadcast from rank 0)
+        packed_nodes, nodes = np.ascontiguousarray(packed, np.uint32).reshape(-1, 4), None
+        assert api.bvh_validate(packed_nodes) == prim_count
+        wl.build_seconds = 0.0
     t0 = time.time()
-    positions, hits = api.primary_positions(builder.m_packedNodes, sc.eye, sc.target, sc.fovy, W, H, threads)
+    positions, hits = api.primary_positions(packed_nodes, sc.eye, sc.target, sc.fovy, W, H, threads)
     say(f"G-buffer positions {W}x{H} in {time.time() - t0:.2f}s ({hits / (W * H) * 100:.1f}% of pixels hit geometry)")
 
     wl.scene = sc
     wl.W, wl.H, wl.spp = W, H, spp
     wl.prim_count = prim_count
     wl.vertices, wl.indices = verts, indices
-    wl.packed = builder.m_packedNodes
-    wl.nodes = builder.m_nodes
+    wl.packed = packed_nodes
+    wl.nodes = nodes
     wl.positions = positions
     wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
     if light == "directional":
