@@ -439,7 +439,20 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
         for (int k = 0; k < K; ++k)
             members[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(members[k] >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)members[k]);
-        if constexpr (PREFETCH && K == 1)
+        if constexpr (K == 1 && !PREFETCH) {
+            occluded[0] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(occluded[0] >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)occluded[0]);
+            // leaves are handled inside the asm loop; it only comes back when the packet is finished (cur == END),
+            // dissolves, or (code 2) stands on a node nobody waits on after all its rays got occluded
+            const uint32_t code = packetDescendLeaf(form, p.bvh, r, cur, members, wait, occluded, budget, acc, thr, window);
+            if (code == 2) {
+                cur = waveMinU32(wait[0]);
+                members[0] = __builtin_amdgcn_ballot_w64(wait[0] == cur);
+                leaf = true;                         // (keeps the loop going; the leaf block below is skipped)
+                continue;
+            }
+            leaf = false;
+        } else if constexpr (PREFETCH && K == 1)
             leaf = packetDescendPrefetch(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;
         else
             leaf = packetDescend(form, p.bvh, r, cur, members, wait, budget, acc, thr, window) != 0;

@@ -199,17 +199,137 @@ def loop_prefetch(form):
     return L
 
 
-def emit_asm(K, form, ind, prefetch=False):
-    lines = loop_prefetch(form) if prefetch else loop(K, form)
+
+def loop_leaf(form):
+    """K = 1, leaves handled inside the loop (no exit to compiled code per leaf visit).
+
+    Triangle test = RayTracedShadows.comp:41-59 operation for operation (separate mul/sub/add, no contraction;
+    dot products left to right; 1/det with the correctly rounded divide sequence hipcc emits for `1.0f / x`).
+    Extra fixed SGPRs: s[56:59] = tail vec4 (v0), s[60:63] = reject masks.  Returns 0 (finished: cur = END, or
+    dissolve: cur = node to continue at) or 2 (every ray on the leaf got occluded and nobody waits on its miss
+    link: the caller finds the lowest waiting node)."""
+    test = test_generic(0) if form == 8 else test_ordered(0, form)
+    r = "s[54:55]"
+    L = ["s_lshl_b32 s52, %[cur], 5",
+         "s_branch 2f",
+         "5:",
+         "s_add_u32 s52, s52, 32",
+         "2:",
+         "s_load_dwordx8 s[40:47], %[base], s52",
+         "s_waitcnt lgkmcnt(0)",
+         "s_cmp_lg_u32 s43, -1",
+         "s_cbranch_scc1 9f"]
+    L += test
+    L += [f"s_andn2_b64 s[50:51], %[m0], {r}",
+          "s_cbranch_scc0 5b",
+          "s_mov_b64 s[48:49], exec",
+          "s_mov_b64 exec, s[50:51]",
+          "v_mov_b32 %[w0], s47",
+          "s_mov_b64 exec, s[48:49]",
+          f"s_and_b64 %[m0], %[m0], {r}",
+          "s_cbranch_scc1 5b",
+          "4:",                                           # side-step to s47
+          "s_lshl_b32 s52, s47, 5",
+          "s_cmp_eq_u32 s47, -1",
+          "s_cbranch_scc1 6f",
+          "v_cmp_eq_u32 %[m0], s47, %[w0]",
+          "s_bcnt1_i32_b64 s50, %[m0]",
+          "s_add_u32 %[acc], %[acc], s50",
+          "s_sub_u32 %[budget], %[budget], 1",
+          "s_cbranch_scc0 2b",
+          "v_cmp_ne_u32 s[48:49], -1, %[w0]",
+          "s_or_b64 s[48:49], s[48:49], %[m0]",
+          "s_bcnt1_i32_b64 s51, s[48:49]",
+          "s_mul_i32 s51, s51, %[thr]",
+          "s_lshl_b32 s50, %[acc], 4",
+          "s_mov_b32 %[acc], 0",
+          "s_mov_b32 %[budget], %[window]",
+          "s_cmp_lt_u32 s50, s51",
+          "s_cbranch_scc0 2b",
+          "8:",                                           # dissolve
+          "s_mov_b32 %[leaf], 0",
+          "s_lshr_b32 %[cur], s52, 5",
+          "s_branch 7f",
+          "6:",                                           # finished
+          "s_mov_b32 %[leaf], 0",
+          "s_mov_b32 %[cur], -1",
+          "s_branch 7f",
+          # ---- leaf: e0 = s40-42, tail index s43, e1 = s44-46, next = s47 -------------------------------------
+          "9:",
+          "s_lshl_b32 s53, s43, 4",
+          "s_load_dwordx4 s[56:59], %[base], s53",        # v0 (arrives while s1, det and 1/det are computed)
+          "v_mul_f32 %[t0], s46, %[dy0]", "v_mul_f32 %[t1], s45, %[dz0]", "v_sub_f32 %[t0], %[t0], %[t1]",   # s1.x = d.y*e1.z - e1.y*d.z
+          "v_mul_f32 %[t1], s44, %[dz0]", "v_mul_f32 %[t2], s46, %[dx0]", "v_sub_f32 %[t1], %[t1], %[t2]",   # s1.y = d.z*e1.x - e1.z*d.x
+          "v_mul_f32 %[t2], s45, %[dx0]", "v_mul_f32 %[t3], s44, %[dy0]", "v_sub_f32 %[t2], %[t2], %[t3]",   # s1.z = d.x*e1.y - e1.x*d.y
+          "v_mul_f32 %[t3], s40, %[t0]", "v_mul_f32 %[t4], s41, %[t1]", "v_add_f32 %[t3], %[t3], %[t4]",
+          "v_mul_f32 %[t4], s42, %[t2]", "v_add_f32 %[t3], %[t3], %[t4]",                                     # det = dot(s1, e0)
+          # invd = 1.0f / det, correctly rounded (the sequence hipcc emits)
+          "v_div_scale_f32 %[t5], s[60:61], %[t3], %[t3], 1.0",
+          "v_rcp_f32 %[t7], %[t5]",
+          "v_div_scale_f32 %[t6], vcc, 1.0, %[t3], 1.0",
+          "v_fma_f32 %[t8], -%[t5], %[t7], 1.0",
+          "v_fmac_f32 %[t7], %[t8], %[t7]",
+          "v_mul_f32 %[t8], %[t6], %[t7]",
+          "v_fma_f32 %[t9], -%[t5], %[t8], %[t6]",
+          "v_fmac_f32 %[t8], %[t9], %[t7]",
+          "v_fma_f32 %[t5], -%[t5], %[t8], %[t6]",
+          "v_div_fmas_f32 %[t5], %[t5], %[t7], %[t8]",
+          "v_div_fixup_f32 %[t4], %[t5], %[t3], 1.0",                                                          # invd
+          "s_waitcnt lgkmcnt(0)",
+          "v_subrev_f32 %[t5], s56, %[ox0]", "v_subrev_f32 %[t6], s57, %[oy0]", "v_subrev_f32 %[t7], s58, %[oz0]",   # dd = o - v0
+          "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
+          "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]", # b1 = dot(dd, s1) * invd
+          "v_mul_f32 %[t9], s42, %[t6]", "v_mul_f32 %[t10], s41, %[t7]", "v_sub_f32 %[t9], %[t9], %[t10]",     # s2.x = dd.y*e0.z - e0.y*dd.z
+          "v_mul_f32 %[t10], s40, %[t7]", "v_mul_f32 %[t11], s42, %[t5]", "v_sub_f32 %[t10], %[t10], %[t11]",  # s2.y = dd.z*e0.x - e0.z*dd.x
+          "v_mul_f32 %[t11], s41, %[t5]", "v_mul_f32 %[t12], s40, %[t6]", "v_sub_f32 %[t11], %[t11], %[t12]",  # s2.z = dd.x*e0.y - e0.x*dd.y
+          "v_mul_f32 %[t12], %[dx0], %[t9]", "v_mul_f32 %[t13], %[dy0], %[t10]", "v_add_f32 %[t12], %[t12], %[t13]",
+          "v_mul_f32 %[t13], %[dz0], %[t11]", "v_add_f32 %[t12], %[t12], %[t13]", "v_mul_f32 %[t12], %[t12], %[t4]",   # b2 = dot(d, s2) * invd
+          "v_mul_f32 %[t13], s44, %[t9]", "v_mul_f32 %[t14], s45, %[t10]", "v_add_f32 %[t13], %[t13], %[t14]",
+          "v_mul_f32 %[t14], s46, %[t11]", "v_add_f32 %[t13], %[t13], %[t14]", "v_mul_f32 %[t13], %[t13], %[t4]",     # t = dot(e1, s2) * invd
+          "v_add_f32 %[t14], %[t8], %[t12]",                                                                            # b1 + b2
+          # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51)
+          "v_cmp_gt_f32 s[60:61], 0, %[t8]",
+          "v_cmp_lt_f32 s[62:63], 1.0, %[t8]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "v_cmp_gt_f32 s[62:63], 0, %[t12]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "v_cmp_lt_f32 s[62:63], 1.0, %[t14]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "v_cmp_gt_f32 s[62:63], 0, %[t13]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "v_cmp_lt_f32 s[62:63], %[tm0], %[t13]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "s_andn2_b64 s[62:63], %[m0], s[60:61]",         # members that hit the triangle: occluded, finished
+          "s_or_b64 %[oc0], %[oc0], s[62:63]",
+          "s_and_b64 s[60:61], %[m0], s[60:61]",           # members that missed: wait on the miss link
+          "s_mov_b64 s[48:49], exec",
+          "s_mov_b64 exec, s[60:61]",
+          "v_mov_b32 %[w0], s47",
+          "s_mov_b64 exec, s[62:63]",
+          "v_mov_b32 %[w0], -1",
+          "s_mov_b64 exec, s[48:49]",
+          "s_lshl_b32 s52, s47, 5",
+          "s_cmp_eq_u32 s47, -1",
+          "s_cbranch_scc1 6b",
+          "v_cmp_eq_u32 %[m0], s47, %[w0]",
+          "s_cmp_eq_u64 %[m0], 0",
+          "s_cbranch_scc0 2b",                             # somebody stands on the miss link: go on
+          "s_mov_b32 %[leaf], 2",                          # nobody: the caller looks for the lowest waiting node
+          "s_lshr_b32 %[cur], s52, 5",
+          "7:"]
+    return L
+
+
+def emit_asm(K, form, ind, prefetch=False, leaf=False):
+    lines = loop_leaf(form) if leaf else (loop_prefetch(form) if prefetch else loop(K, form))
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
     outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
     outs += [f'[m{k}] "+s"(members[{k}])' for k in range(K)]
     outs += [f'[w{k}] "+v"(wait[{k}])' for k in range(K)]
-    outs += [f'[t{i}] "=&v"(t{i})' for i in range(7)]
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(15 if leaf else 7)]
+    if leaf:
+        outs += ['[oc0] "+s"(occluded[0])']
     ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
     for k in range(K):
         ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
-    regs = list(range(40, 54)) + list(range(54, 64)) if prefetch else list(range(40, 53)) + list(range(54, 54 + 2 * K))
+        if leaf:
+            ins += [f'[d{a}{k}] "v"(r[{k}].d.{a})' for a in AX] + [f'[tm{k}] "v"(r[{k}].tmax)']
+    regs = list(range(40, 64)) if (prefetch or leaf) else list(range(40, 53)) + list(range(54, 54 + 2 * K))
     clob = [f'"s{i}"' for i in regs] + ['"vcc"', '"scc"']
     return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
             f"{ind}    : {', '.join(clob)});\n")
@@ -239,6 +359,22 @@ def main():
         o.append("    return leaf;")
         o.append("}")
         o.append("")
+    o.append("// K = 1 with the leaves handled inside the loop (see loop_leaf in the generator).")
+    o.append("__device__ __forceinline__ uint32_t packetDescendLeaf(uint32_t form, const void* base, const Ray (&r)[1],")
+    o.append("                                                    uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
+    o.append("                                                    uint64_t (&occluded)[1], int32_t& budget, uint32_t& acc,")
+    o.append("                                                    uint32_t thr, uint32_t window) {")
+    o.append("    uint32_t leaf;")
+    o.append("    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;")
+    o.append("    switch (form) {")
+    for form in range(9):
+        o.append(f"    case {form}:" if form < 8 else "    default:")
+        o.append(emit_asm(1, form, "        ", leaf=True).rstrip("\n"))
+        o.append("        break;")
+    o.append("    }")
+    o.append("    return leaf;")
+    o.append("}")
+    o.append("")
     o.append("// K = 1 with the sequential successor node prefetched into a second SGPR set (see loop_prefetch).")
     o.append("__device__ __forceinline__ uint32_t packetDescendPrefetch(uint32_t form, const void* base, const Ray (&r)[1],")
     o.append("                                                        uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
