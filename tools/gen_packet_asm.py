@@ -13,9 +13,13 @@ Register plan inside the asm (fixed scratch SGPRs, declared as clobbers):
     s[54:61]  slab-test results of ray sets 0..3 (VALU-written, SALU-read: interlocked by hardware)
 """
 import os
+import re
+import sys
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    "raytracedshadows_amd", "csrc", "rts_packet_asm.inc")
+
+SGPR_BASE = 40   # first of the 24 fixed scratch SGPRs (the text below is written for 40 and relocated)
 
 LO = ["s40", "s41", "s42"]
 HI = ["s44", "s45", "s46"]
@@ -315,8 +319,20 @@ def loop_leaf(form):
     return L
 
 
+def relocate(line):
+    """Moves every fixed scratch register s40..s63 (single or range) to SGPR_BASE.."""
+    d = SGPR_BASE - 40
+    def one(m):
+        return f"s{int(m.group(1)) + d}"
+    def rng(m):
+        return f"s[{int(m.group(1)) + d}:{int(m.group(2)) + d}]"
+    line = re.sub(r"\bs\[(4\d|5\d|6[0-3]):(4\d|5\d|6[0-3])\]", rng, line)
+    return re.sub(r"\bs(4\d|5\d|6[0-3])\b", one, line)
+
+
 def emit_asm(K, form, ind, prefetch=False, leaf=False):
     lines = loop_leaf(form) if leaf else (loop_prefetch(form) if prefetch else loop(K, form))
+    lines = [relocate(l) for l in lines]
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
     outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
     outs += [f'[m{k}] "+s"(members[{k}])' for k in range(K)]
@@ -330,12 +346,15 @@ def emit_asm(K, form, ind, prefetch=False, leaf=False):
         if leaf:
             ins += [f'[d{a}{k}] "v"(r[{k}].d.{a})' for a in AX] + [f'[tm{k}] "v"(r[{k}].tmax)']
     regs = list(range(40, 64)) if (prefetch or leaf) else list(range(40, 53)) + list(range(54, 54 + 2 * K))
-    clob = [f'"s{i}"' for i in regs] + ['"vcc"', '"scc"']
+    clob = [f'"s{i + SGPR_BASE - 40}"' for i in regs] + ['"vcc"', '"scc"']
     return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
             f"{ind}    : {', '.join(clob)});\n")
 
 
 def main():
+    global SGPR_BASE
+    if len(sys.argv) > 1:
+        SGPR_BASE = int(sys.argv[1])
     o = ["// GENERATED by tools/gen_packet_asm.py -- do not edit by hand.",
          "// Descent loop of the packet kernels (see rts_kernels.hip, 'V_PACKET').  Walks inner nodes from `cur`",
          "// until the packet stands on a leaf (returns 1, cur = that leaf), runs out of nodes (returns 0, cur = END)",
