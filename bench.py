@@ -206,6 +206,19 @@ def main():
                              "frac > 1 means the node stream is served from L2/Infinity Cache, not HBM"},
     }
 
+    # informative extra: instruction-issue view of the same launch.  VALU wave-instructions per launch
+    # come from the committed rocprofv3 PMC pass of this kernel + workload, the ceiling from the microbenchmark
+    # (profiles/r01/microbench_valu_issue.log); the duration is this run's.
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "packet_final_city4k_summary.json")))
+        if args.config == "city_4k" and kname == "shadowMaskPacketKernel<1>" and not striped:
+            valu = prof["counters_avg_per_dispatch"]["SQ_INSTS_VALU"]
+            per_clk = valu / (avg_launch_s * 2.4e9 * 1024)
+            result["valu_issue"] = {"achieved": round(per_clk, 3), "peak": 0.325, "unit": "wave64 VALU instr / clk / SIMD (2.4 GHz)",
+                                    "frac": round(per_clk / 0.325, 3), "valu_instr_per_launch": int(valu)}
+    except Exception:
+        pass
+
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on the host cores, same frame ---------------
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         threads = oracle.max_threads()
