@@ -59,3 +59,20 @@ def test_missing_library_fails_loudly_but_build_helper_still_imports():
     bad = subprocess.run([sys.executable, "-c", "import raytracedshadows_amd as r; r.ShadowContext"], env=env,
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "is missing" in bad.stderr
+
+
+def test_generated_asm_include_is_up_to_date(tmp_path):
+    """rts_packet_asm.inc is generated: the committed file must be what tools/gen_packet_asm.py produces."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_packet_asm", os.path.join(ROOT, "tools", "gen_packet_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "out.inc")
+    import sys
+    argv, sys.argv = sys.argv, ["gen_packet_asm.py"]
+    try:
+        gen.main()
+    finally:
+        sys.argv = argv
+    assert open(gen.OUT).read() == committed
