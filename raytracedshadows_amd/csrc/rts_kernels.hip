@@ -5,6 +5,11 @@
 // SURVEY.md Appendix A.  One shadow ray per lane, one 8x8 pixel tile per wave64 (the reference's
 // local_size 8x8, comp:127).  No MFMA: the work is branchy scalar/vec3 arithmetic.
 //
+// Two families of kernels: lane-per-ray (each lane walks its own ray with vector loads: `straight`,
+// `while-while`, `postpone`, `share`) and PACKET (the wave walks the union of its rays' paths, the node
+// is wave-uniform and fetched with one scalar load; descent + leaf test hand-written in gfx950
+// assembly, rts_packet_asm.inc).  DESIGN.md section 4 has the measurements behind every choice.
+//
 // Bit-exactness contract: this file is compiled with -ffp-contract=off and
 // correctly rounded divide/sqrt; the slab test has an EXACT form (GLSL compare-select min/max,
 // NaN-propagating) and a FAST form (v_min3/v_max3) that is only taken when no NaN can occur for any
@@ -329,16 +334,13 @@ __device__ __forceinline__ bool traversePostpone(const NodeStream& bvh, const Ra
 // same arithmetic), so the mask is bit-identical.  Measured on the headline frame an 8x8 tile visits
 // 41 distinct nodes while its longest single ray visits 35 (oracle: orc_tile_union_stats).
 //
-// Incoherent waves (random generic rays) would visit up to 64x the nodes; the packet therefore has a
-// step budget, after which its lanes are handed to the lane-per-ray loop, each from its own node.
+// Incoherent waves (random generic rays) would visit up to 64x the nodes; the packet therefore checks
+// its own coherence every few side-steps and, when it no longer pays, dissolves: its lanes are handed
+// to the lane-per-ray loop (with work sharing), each from the node it stands or waits on.
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x8* ConstNodePtr;
 typedef const __attribute__((address_space(4))) u32x4* ConstVec4Ptr;
-
-// A coherent 8x8 tile needs 40-70 packet steps on the BASELINE scenes (union of its rays' paths); 64
-// unrelated rays would need thousands.  After TraceParams::packetBudget side-steps the packet dissolves and
-// each ray goes on alone.
 
 __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
     // smallest value over all 64 lanes (inactive-by-value lanes carry END = 0xFFFFFFFF)
