@@ -131,6 +131,7 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *   "packet_share"  a packet dissolves when it picks up fewer than share/16 of its live rays per side-step (default 4)
  *   "block_waves"   waves per workgroup of the packet kernels: 1 (default) or 4
  *   "xcd_swizzle"   1 = contiguous image chunk per XCD (default 0: measured slower)
+ *   "lds_pad"       experiment: extra dynamic LDS bytes per one-wave packet workgroup (throttles occupancy; default 0)
  *   "wave_stats"    diagnostics, see rts_ctx_read_wave_stats
  *   get only: "bvh_finite", "bvh_ordered" (which slab-test forms the uploaded stream allows) */
 int rts_ctx_set_option(rts_ctx* ctx, const char* key, int value);

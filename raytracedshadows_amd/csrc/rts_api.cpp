@@ -29,6 +29,7 @@ struct rts_ctx {
     int packetBudget = 8;
     int packetShare = 4;
     int blockWaves = 1;
+    int ldsPad = 0;              // experiment knob: dynamic LDS bytes per workgroup (throttles occupancy)
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
@@ -185,6 +186,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "xcd_swizzle")) { c->swizzle = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "packet_budget")) { if (value < 1) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
+    if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
@@ -260,7 +262,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
-    return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream));
+    return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, (uint32_t)c->ldsPad));
 }
 
 int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_light* light,

@@ -46,7 +46,7 @@ struct TraceParams {
 
 const char* kernelName(int variant, bool mask);
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH);   // pixels covered by one block
-hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream);
+hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad = 0);
 hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream);
 
 } // namespace rts

@@ -703,12 +703,12 @@ void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* block
     *blockH = f * (variant == V_PACKET4 ? 16u : 8u);
 }
 
-hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream) {
+hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad) {
     dim3 grid(p.gridBlocks), block(256);
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
-        case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, 0, stream, p); break;
+        case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, ldsPad, stream, p); break;
         case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1>), grid, b1, 0, stream, p); break;
         case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1>), grid, b1, 0, stream, p); break;
         case V_PACKET_PF: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true>), grid, b1, 0, stream, p); break;
