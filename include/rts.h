@@ -183,7 +183,10 @@ const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
  * order[i] (a permutation of 0..count-1; NULL or 0 restores the natural order).  Speed only. */
 int rts_ctx_set_tile_order(rts_ctx* ctx, const uint32_t* order, size_t count);
 /* Diagnostics (tools/wave_stats.py): after rts_ctx_set_option(ctx, "wave_stats", n_waves) the packet
- * kernels record {start clock, end clock, side-steps left, block xy} per wave; this copies them out. */
+ * kernels record 4 x u64 per wave: start clock, end clock, {dissolved flag (bit 0) | lane-per-ray iterations after the
+ * dissolve (bits 8-31) | clocks from start to the dissolve (32-63)}, {tile x (48-63) | tile y (32-47) | lane-steps in
+ * those iterations (0-31)};
+ * this copies them out. */
 int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
 
 #ifdef __cplusplus

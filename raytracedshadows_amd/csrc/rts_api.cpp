@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <string>
+#include <vector>
 
 using rts::TraceParams;
 
@@ -25,7 +25,7 @@ struct rts_ctx {
     // staging for the host-pointer entries
     void* d_in = nullptr; size_t inBytes = 0;
     void* d_out = nullptr; size_t outBytes = 0;
-    std::string lastKernel;
+    const char* lastKernel = "";
     int packetBudget = 8;
     int packetShare = 4;
     int blockWaves = 1;
@@ -171,12 +171,15 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
         float lo[3], hi[3]; memcpy(lo, &packed[2 * i], 12); memcpy(hi, &packed[2 * i + 1], 12);
         ordered = lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2];
     }
-    if (count * 16 >= (1ull << 32)) return RTS_ERR_BAD_BVH;            // 32-bit byte offsets on the device
+    if (count * 16 >= 0xFFFFFF00ull) return RTS_ERR_BAD_BVH;           // 32-bit byte offsets on the device (top 256 B = "nothing")
     RTS_HIP(hipSetDevice(c->device));
-    if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
-    RTS_HIP(hipMalloc(&c->d_bvh, count * 16 + 64));   // + slack: the prefetching packet loop reads one node ahead
-    RTS_HIP(hipMemcpy(c->d_bvh, packed, count * 16, hipMemcpyHostToDevice));
-    c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
+    // the context only changes once the new copy is complete; a failure leaves it without a BVH, never with a torn one
+    if (c->d_bvh) { void* old = c->d_bvh; c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; RTS_HIP(hipFree(old)); }
+    void* d = nullptr;
+    RTS_HIP(hipMalloc(&d, count * 16 + 64));          // + slack: the prefetching packet loop reads one node ahead
+    hipError_t e = hipMemcpy(d, packed, count * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hipStatus(e); }
+    c->d_bvh = d; c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
     return RTS_OK;
 }
 
@@ -220,6 +223,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (!c || !k || !d_positions || !d_mask || W == 0 || H == 0 || row_begin > row_end || row_end > H)
         return RTS_ERR_INVALID_ARG;
     if (light && (light->type > RTS_LIGHT_POINT || light->nsamples > 64)) return RTS_ERR_INVALID_ARG;
+    if ((uint64_t)W * H > (1ull << 31)) return RTS_ERR_INVALID_ARG;      // tile counts are 32-bit on the device
     TraceParams p;
     int s = fillParams(c, p);
     if (s != RTS_OK) return s;
@@ -306,7 +310,7 @@ int rts_trace_shadow_mask(rts_ctx* c, const rts_constants* k, const rts_light* l
 }
 
 int rts_trace_rays_device(rts_ctx* c, const rts_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
-    if (!c || (n && (!d_rays || !d_out))) return RTS_ERR_INVALID_ARG;
+    if (!c || (n && (!d_rays || !d_out)) || n > (1ull << 38)) return RTS_ERR_INVALID_ARG;   // grid.x is 31-bit
     TraceParams p;
     int s = fillParams(c, p);
     if (s != RTS_OK) return s;
@@ -384,16 +388,16 @@ int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
     RTS_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return RTS_OK;
 }
-const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel.c_str() : ""; }
+const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel : ""; }
 
 int rts_ctx_device_ordinal(rts_ctx* c) { return c ? c->device : 0; }
 
 // used by the GPU builder (rts_lbvh.hip): the context takes ownership of a packed stream that is already on the
 // device (finite vertices were checked there; LBVH boxes are min <= max by construction)
 int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t P) {
-    if (!c || !d_packed || count != (size_t)5 * P - 2 || count * 16 >= (1ull << 32)) return RTS_ERR_INVALID_ARG;
+    if (!c || !d_packed || count != (size_t)5 * P - 2 || count * 16 >= 0xFFFFFF00ull) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
-    if (c->d_bvh) { RTS_HIP(hipFree(c->d_bvh)); c->d_bvh = nullptr; }
+    if (c->d_bvh) { void* old = c->d_bvh; c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; RTS_HIP(hipFree(old)); }
     c->d_bvh = d_packed;
     c->bvhVec4 = count; c->P = P; c->bvhFinite = true; c->bvhOrdered = true;
     return RTS_OK;
@@ -413,8 +417,12 @@ int rts_ctx_set_tile_order(rts_ctx* c, const uint32_t* order, size_t count) {
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_tileOrder) { RTS_HIP(hipFree(c->d_tileOrder)); c->d_tileOrder = nullptr; c->tileOrderCount = 0; }
     if (!order || count == 0) return RTS_OK;
-    std::string seen(count, 0);
-    for (size_t i = 0; i < count; ++i) { if (order[i] >= count || seen[order[i]]) return RTS_ERR_INVALID_ARG; seen[order[i]] = 1; }
+    try {
+        std::vector<uint8_t> seen(count, 0);
+        for (size_t i = 0; i < count; ++i) { if (order[i] >= count || seen[order[i]]) return RTS_ERR_INVALID_ARG; seen[order[i]] = 1; }
+    } catch (...) {
+        return RTS_ERR_CAPACITY;                   // no exception crosses the C ABI
+    }
     RTS_HIP(hipMalloc((void**)&c->d_tileOrder, count * 4));
     RTS_HIP(hipMemcpy(c->d_tileOrder, order, count * 4, hipMemcpyHostToDevice));
     c->tileOrderCount = count;

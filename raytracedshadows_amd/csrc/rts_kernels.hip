@@ -172,21 +172,37 @@ __device__ __forceinline__ bool traverseStraight(const NodeStream& bvh, const Ra
 // rays scatter (atrium: one ray visiting 381 nodes at L2 latency) is spread over all 64 lanes.
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t SHARE_MIN_IDLE = 8;
+static constexpr uint32_t OOB_VEC4 = 0x0FFFFFF0u;      // vec4 index whose byte offset (0xFFFFFF00) lies beyond any accepted stream
+
+__device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the loop and active lanes summed over them
+    bool on = false;
+    uint32_t iterations = 0, laneSteps = 0;
+    uint64_t tDissolve = 0;     // clock when the (last) packet of this wave dissolved
+};
 
 template <bool FAST>
-__device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots) {
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    uint32_t node = live ? start : END, bound = END, owner = lane;
+__device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
+                                              ShareDiag* diag = nullptr) {
+    uint32_t node = live ? start : END, bound = END, owner = laneId();
     uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
+    // The loop is rotated: the node of the NEXT iteration is requested before the triangle of this one is tested.
+    // A leaf's successor is known without any arithmetic (its miss link), and the triangle's v0 is a load that
+    // depends on the node just fetched; waiting for it before moving on costs a second memory latency in every
+    // iteration in which any lane stands on a leaf.  Here v0 and the next node travel together (v0 first: loads
+    // return in order), and the triangle test runs while the next node is still on its way.
+    // All three loads of an iteration are issued unconditionally (a lane with nothing to fetch asks for an index
+    // beyond the buffer: the range check answers 0 without touching memory).  With a load inside a divergent branch
+    // the compiler can only wait for "all outstanding loads" at the first use, which would serialise them again.
+    bool active = node < bound;
+    u32x4 a = bvh.vec4(active ? node * 2u : OOB_VEC4), b = bvh.vec4(active ? node * 2u + 1u : OOB_VEC4);
     for (;;) {
-        // pieces of an owner that is already known to be occluded have nothing left to prove
-        if ((occludedOwners >> owner) & 1ull) node = END;
-        const bool active = node < bound;
         const uint64_t act = __builtin_amdgcn_ballot_w64(active);
         if (act == 0) break;
-        u32x4 a{ 0, 0, 0, END }, b{ 0, 0, 0, END };
-        if (active) { a = bvh.vec4(node * 2); b = bvh.vec4(node * 2 + 1); }
+        if (diag && diag->on) { diag->iterations += 1u; diag->laneSteps += (uint32_t)__builtin_popcountll(act); }
+        uint32_t next = node;                                        // lanes that do not move keep their (finished) range
         if ((iter++ & 3u) == 0) {
             const uint64_t idle = ~act;
             const bool canGive = active && b.w < bound;              // there is a second part to give away
@@ -194,6 +210,7 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
             const uint32_t nIdle = (uint32_t)__builtin_popcountll(idle), nGive = (uint32_t)__builtin_popcountll(givers);
             if (nIdle >= SHARE_MIN_IDLE && nGive != 0) {
                 const uint32_t pairs = nIdle < nGive ? nIdle : nGive;
+                const uint32_t lane = laneId();                      // (recomputed: cheaper than a register held across the walk)
                 const uint32_t below = (1u << (lane & 31u)) - 1u;
                 const uint32_t rankG = lane < 32 ? __builtin_popcount((uint32_t)givers & below)
                                                  : __builtin_popcount((uint32_t)givers) + __builtin_popcount((uint32_t)(givers >> 32) & below);
@@ -222,32 +239,39 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
                 const uint32_t srcOwner = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)owner);
                 if (takes) {
                     r.o = F3{ ox, oy, oz }; r.d = F3{ dx, dy, dz }; r.inv = F3{ ix, iy, iz }; r.tmax = tm;
-                    node = srcNext; bound = srcBound; owner = srcOwner;   // starts walking next iteration
+                    next = srcNext; bound = srcBound; owner = srcOwner;   // its first node is requested below
                 }
                 if (gives) bound = b.w;                              // keeps [node, next(node))
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        bool hitNow = false;
+        const bool leaf = active && a.w != END;
+        const u32x4 v0 = bvh.vec4(leaf ? a.w : OOB_VEC4);
         if (active) {
-            if (a.w != END) {
-                u32x4 t = bvh.vec4(a.w);
-                hitNow = triHit(r, xyz(t), xyz(a), xyz(b));
-                node = hitNow ? END : b.w;
+            if (leaf) {
+                next = b.w;
             } else {
                 const bool h = boxHit<FAST>(r, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z),
                                             __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                node = h ? node + 1 : b.w;
+                next = h ? node + 1 : b.w;
             }
         }
+        // request the next node, then test the triangle while it travels
+        const bool nextActive = next < bound;
+        const uint32_t nv = nextActive ? next * 2u : OOB_VEC4;
+        const u32x4 na = bvh.vec4(nv), nb = bvh.vec4(nv + 1u);
+        const bool hitNow = leaf && triHit(r, xyz(v0), xyz(a), xyz(b));
         uint64_t hits = __builtin_amdgcn_ballot_w64(hitNow);
         while (hits) {                                               // rare: record the owners that just got occluded
             const int l = __builtin_ctzll(hits);
             occludedOwners |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)owner, l);
             hits &= hits - 1;
         }
+        node = next; a = na; b = nb;
+        // pieces of an owner that is known to be occluded have nothing left to prove
+        active = nextActive && !((occludedOwners >> owner) & 1ull);
     }
-    return (occludedOwners >> lane) & 1ull;
+    return (occludedOwners >> laneId()) & 1ull;
 }
 
 // V_WHILEWHILE: descend inner nodes until every lane of the wave holds a leaf (or is done), then
@@ -380,7 +404,7 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], uint32_t* lds,
-                                               int32_t* sideStepsLeft = nullptr) {
+                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr) {
     const ConstNodePtr nodes = (ConstNodePtr)(uintptr_t)p.bvh;
     const ConstVec4Ptr vec4s = (ConstVec4Ptr)(uintptr_t)p.bvh;
     uint64_t members[K], occluded[K];
@@ -494,10 +518,11 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     if (sideStepsLeft) *sideStepsLeft = dissolve ? -1 : 0;
     if (cur != END) {
         // dissolved (not coherent enough for a packet): every unfinished ray continues alone
+        if (shareDiag && shareDiag->on) shareDiag->tDissolve = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
-            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds);
+            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
             result[k] = result[k] || h;
         }
     }
@@ -593,8 +618,10 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // 8x8 sub-tiles of its wave tile), a 256-thread block is 2x2 wave tiles.
 // WPB = waves per block: 4 (block = 2x2 wave tiles) or 1 (block = one wave tile, so that a finished wave
 // frees its slot without waiting for three siblings).
-template <int K, int WPB, bool PREFETCH = false>
-__global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p) {
+// SOFT = more than one sample per pixel: only then the G-buffer position has to stay in registers across the walk.
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
+void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
@@ -618,9 +645,11 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
         }
     }
     const NodeStream bvh = openStream(p);
-    const uint32_t ns = p.nsamples > 1 ? p.nsamples : 1u;
+    const uint32_t ns = SOFT ? p.nsamples : 1u;
     const uint64_t tStart = p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
     int32_t left = 0;
+    ShareDiag shareDiag;
+    shareDiag.on = p.waveStats != nullptr;
     uint32_t lit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lit[k] = 0;
@@ -629,7 +658,7 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
         bool occluded[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
-        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left);
+        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -642,8 +671,10 @@ __global__ __launch_bounds__(64 * WPB) void shadowMaskPacketKernel(TraceParams p
         uint64_t* o = p.waveStats + ((size_t)blockIdx.x * WPB + wave) * 4;
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
-        o[2] = (uint64_t)(uint32_t)left;
-        o[3] = ((uint64_t)bx << 32) | by;
+        // dissolved flag | lane-per-ray iterations after the dissolve | clocks from start to the dissolve
+        o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
+               ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);
+        o[3] = ((uint64_t)bx << 48) | ((uint64_t)(by & 0xFFFFu) << 32) | shareDiag.laneSteps;   // ... and the lane-steps in them
     }
 }
 
@@ -705,13 +736,14 @@ void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* block
 
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad) {
     dim3 grid(p.gridBlocks), block(256);
+    const bool soft = p.nsamples > 1;
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
-        case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1>), grid, b1, ldsPad, stream, p); break;
-        case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1>), grid, b1, 0, stream, p); break;
-        case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1>), grid, b1, 0, stream, p); break;
-        case V_PACKET_PF: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true>), grid, b1, 0, stream, p); break;
+        case V_PACKET: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p); break;
+        case V_PACKET2: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1, false, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1, false, false>), grid, b1, 0, stream, p); break;
+        case V_PACKET4: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1, false, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1, false, false>), grid, b1, 0, stream, p); break;
+        case V_PACKET_PF: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true, false>), grid, b1, 0, stream, p); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -721,10 +753,10 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     case V_WHILEWHILE: hipLaunchKernelGGL(shadowMaskKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(shadowMaskKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
     case V_SHARE: hipLaunchKernelGGL(shadowMaskKernel<V_SHARE>, grid, block, 0, stream, p); break;
-    case V_PACKET: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4>), grid, block, 0, stream, p); break;
-    case V_PACKET2: hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4>), grid, block, 0, stream, p); break;
-    case V_PACKET4: hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4>), grid, block, 0, stream, p); break;
-    case V_PACKET_PF: hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true>), grid, block, 0, stream, p); break;
+    case V_PACKET: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, false>), grid, block, 0, stream, p); break;
+    case V_PACKET2: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4, false, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<2, 4, false, false>), grid, block, 0, stream, p); break;
+    case V_PACKET4: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4, false, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<4, 4, false, false>), grid, block, 0, stream, p); break;
+    case V_PACKET_PF: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, false>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

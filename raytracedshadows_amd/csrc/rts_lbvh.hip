@@ -225,13 +225,18 @@ __global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P 
 
 struct DeviceArena {            // frees everything it handed out, whatever path leaves the function
     void* ptrs[24]; int n = 0;
+    hipEvent_t ev[2] = { nullptr, nullptr };
     template <typename T> hipError_t get(T** p, size_t bytes) {
         void* v = nullptr;
         hipError_t e = hipMalloc(&v, bytes ? bytes : 16);
         if (e == hipSuccess) { ptrs[n++] = v; *p = (T*)v; }
         return e;
     }
-    void release(void* keep = nullptr) { for (int i = 0; i < n; ++i) if (ptrs[i] != keep) (void)hipFree(ptrs[i]); n = 0; }
+    void release(void* keep = nullptr) {
+        for (int i = 0; i < n; ++i) if (ptrs[i] != keep) (void)hipFree(ptrs[i]);
+        n = 0;
+        for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
 };
 
 #define LB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { arena.release(); return RTS_ERR_HIP + (int)e_; } } while (0)
@@ -269,8 +274,8 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
 
     LB_HIP(hipMemcpy(d_verts, vertices, vertex_floats * 4, hipMemcpyHostToDevice));
     LB_HIP(hipMemcpy(d_idx, indices, (size_t)P * 12, hipMemcpyHostToDevice));
-    hipEvent_t ev0, ev1;
-    LB_HIP(hipEventCreate(&ev0)); LB_HIP(hipEventCreate(&ev1));
+    LB_HIP(hipEventCreate(&arena.ev[0])); LB_HIP(hipEventCreate(&arena.ev[1]));
+    const hipEvent_t ev0 = arena.ev[0], ev1 = arena.ev[1];
     LB_HIP(hipEventRecord(ev0, nullptr));
 
     const uint32_t boxInit[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0 };
@@ -283,7 +288,7 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
     hipLaunchKernelGGL(leafBoxesKernel, gridP, block, 0, nullptr, b);
     uint32_t flag = 0;
     LB_HIP(hipMemcpy(&flag, b.flags, 4, hipMemcpyDeviceToHost));
-    if (flag) { arena.release(); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return RTS_ERR_NONFINITE; }
+    if (flag) { arena.release(); return RTS_ERR_NONFINITE; }
 
     const uint64_t* sortedKeys = b.keys;
     const uint32_t* sortedOrder = b.order;
@@ -304,7 +309,7 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
             if ((sweep & 7) == 7 || sweep < 2) LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
         }
         LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
-        if (left != 0) { arena.release(); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return RTS_ERR_BAD_BVH; }
+        if (left != 0) { arena.release(); return RTS_ERR_BAD_BVH; }
         hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, sortedOrder, (uint32_t*)d_packed);
     } else {
         hipLaunchKernelGGL(emitSingleKernel, dim3(1), dim3(64), 0, nullptr, b, (uint32_t*)d_packed);
@@ -314,7 +319,6 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
     LB_HIP(hipGetLastError());
     float ms = 0;
     LB_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     if (build_ms) *build_ms = ms;
     if (out_packed) LB_HIP(hipMemcpy(out_packed, d_packed, count * 16, hipMemcpyDeviceToHost));
     if (install) {

@@ -263,6 +263,13 @@ def test_error_behaviour(ctx):
         assert e.value.status == 1
         with pytest.raises(api.RtsError):
             fresh.set_option("no_such_option", 1)
+        d = fresh.malloc(64)
+        try:                                      # frames beyond 2^31 pixels are refused before anything is touched
+            with pytest.raises(api.RtsError) as e:
+                fresh.trace_shadow_mask_device(k, d, 65536, 65536, d)
+            assert e.value.status == 1
+        finally:
+            fresh.free(d)
         assert fresh.trace_rays(np.zeros((0, 8), np.float32)).size == 0            # empty input is fine
     finally:
         fresh.close()

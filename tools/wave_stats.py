@@ -47,7 +47,7 @@ def main():
                 ctx.set_option("wave_stats", 0)
                 t0, t1 = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64)
                 ok = t1 > 0
-                t0, t1, left = t0[ok], t1[ok], st[ok, 2].astype(np.int64)
+                t0, t1, left = t0[ok], t1[ok], -(st[ok, 2] & np.uint64(1)).astype(np.int64)
                 left = np.where(left > 2**31, left - 2**32, left)
                 base = t0.min()
                 dur = t1 - t0
@@ -66,7 +66,7 @@ def main():
                     print(f"    {q}% of waves finished by {np.percentile(late, q):.1f} us")
                 top = order[:5]
                 print("    longest waves: " + ", ".join(
-                    f"dur {dur[i] * tick_us:.1f}us start {(t0[i] - base) * tick_us:.1f}us used {used[i]} blk({int(st[ok][i, 3] >> np.uint64(32))},{int(st[ok][i, 3] & np.uint64(0xffffffff))})"
+                    f"dur {dur[i] * tick_us:.1f}us start {(t0[i] - base) * tick_us:.1f}us used {used[i]} blk({int(st[ok][i, 3] >> np.uint64(48))},{int((st[ok][i, 3] >> np.uint64(32)) & np.uint64(0xffff))})"
                     for i in top))
         ctx.free(d_pos)
         ctx.free(d_mask)
