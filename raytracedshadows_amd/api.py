@@ -299,6 +299,11 @@ class ShadowContext:
         _check(_lib.rts_trace_rays(self._h, _ptr(rays), rays.shape[0], _ptr(out)), "rts_trace_rays")
         return out
 
+    def trace_rays_device(self, d_rays, n, d_out, stream=None):
+        """Device-pointer form of :meth:`trace_rays` (asynchronous on ``stream``)."""
+        _check(_lib.rts_trace_rays_device(self._h, C.c_void_p(d_rays), n, C.c_void_p(d_out), C.c_void_p(stream or 0)),
+               "rts_trace_rays_device")
+
     # -- plumbing ---------------------------------------------------------------------------
     def malloc(self, nbytes):
         p = C.c_void_p()

@@ -234,7 +234,8 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.W = W; p.H = H; p.rowBegin = row_begin; p.rowEnd = row_end;
     p.bandRows = band_rows; p.nStripes = n_stripes; p.stripe = stripe;
     // V_AUTO: a packet's steps are a dependent chain, so it needs several waves per SIMD to overlap them;
-    // a launch with fewer than ~4 waves per SIMD is faster lane-per-ray.  (Bigger packets, V_PACKET2/4, were
+    // a launch with fewer than ~4 waves per SIMD is faster lane-per-ray (with in-wave work sharing: measured
+    // 5-20 % ahead of the plain loop on every small frame).  (Bigger packets, V_PACKET2/4, were
     // measured slower or equal on every BASELINE config and are kept as selectable variants only.)
     int variant = c->variant;
     uint32_t rows = row_end - row_begin;
@@ -243,7 +244,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows;
     }
     const uint64_t pixels = (uint64_t)W * rows;
-    if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_STRAIGHT;
+    if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_SHARE;
     uint32_t bw, bh;
     rts::tileShape(variant, c->blockWaves, &bw, &bh);
     p.blocksX = (W + bw - 1) / bw;
@@ -253,6 +254,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
     if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) p.waveStats = c->d_waveStats;
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
+    p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;
@@ -317,8 +319,9 @@ int rts_trace_rays_device(rts_ctx* c, const rts_ray* d_rays, size_t n, uint8_t* 
     if (n == 0) return RTS_OK;
     RTS_HIP(hipSetDevice(c->device));
     p.rays = d_rays; p.out = d_out; p.nrays = n;
-    // generic rays carry no coherence promise: lane-per-ray unless the caller asks for a variant
-    const int variant = c->variant == rts::V_AUTO ? rts::V_STRAIGHT : c->variant;
+    // generic rays carry no coherence promise: lane-per-ray with in-wave work sharing unless the caller asks for a
+    // variant (random segments: 2x the plain loop; coherent rays: equal; profiles/r01/generic_rays_variants.log)
+    const int variant = c->variant == rts::V_AUTO ? rts::V_SHARE : c->variant;
     c->lastKernel = rts::kernelName(variant, false);
     ++c->launches;
     return hipStatus(rts::launchTraceRays(variant, p, (hipStream_t)stream));

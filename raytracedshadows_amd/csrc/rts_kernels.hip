@@ -543,6 +543,11 @@ __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream&
 // that co-resident blocks touch neighbouring subtrees of the BVH (per-XCD L2 locality).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool blockToXY(const TraceParams& p, uint32_t bid, uint32_t* bx, uint32_t* by) {
+    if (p.grid2d) {                              // natural order, launched as a blocksX x blocksY grid: no division
+        *bx = blockIdx.x;
+        *by = blockIdx.y;
+        return true;
+    }
     uint32_t b = bid;
     if (p.tileOrder) {                           // dispatch order given by the caller (longest tiles first)
         if (b >= p.nBlocks) return false;
@@ -668,7 +673,7 @@ void shadowMaskPacketKernel(TraceParams p) {
     for (int k = 0; k < K; ++k)
         if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);       // comp:150
     if (p.waveStats && lane == 0) {              // diagnostics: never read by any kernel, never part of an output
-        uint64_t* o = p.waveStats + ((size_t)blockIdx.x * WPB + wave) * 4;
+        uint64_t* o = p.waveStats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave) * 4;
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
         // dissolved flag | lane-per-ray iterations after the dissolve | clocks from start to the dissolve
@@ -736,6 +741,7 @@ void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* block
 
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad) {
     dim3 grid(p.gridBlocks), block(256);
+    if (p.grid2d) grid = dim3(p.blocksX, p.blocksY);
     const bool soft = p.nsamples > 1;
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);

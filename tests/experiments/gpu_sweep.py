@@ -1,5 +1,6 @@
 """Experiment driver (GPU box): every kernel variant x option on the given configs, each checked
-bit-for-bit against the oracle, then timed with hipEvents.  Prints one line per combination."""
+bit-for-bit against the oracle, then timed with hipEvents.  Prints one line per combination.
+Lives under tests/ because it uses the oracle as its checker (test infrastructure, never the product path)."""
 import argparse
 import json
 import os
@@ -8,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -31,7 +32,12 @@ def main():
         sweeps.append((k, [int(v) for v in vs.split(",")]))
 
     for cfg in args.configs.split(","):
-        scene, W, H, light, spp = workloads.CONFIGS[cfg]
+        if "@" in cfg:                                   # ad-hoc size: scene@WxH (point light, 1 sample)
+            scene, wh = cfg.split("@")
+            W, H = (int(v) for v in wh.split("x"))
+            light, spp = "point", 1
+        else:
+            scene, W, H, light, spp = workloads.CONFIGS[cfg]
         wl = workloads.prepare(scene, W, H, light="directional" if args.directional else light, spp=spp, log=print)
         t0 = time.time()
         want, V, L = oracle.shadow_mask(wl.packed, wl.constants.as_array(),

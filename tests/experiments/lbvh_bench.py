@@ -1,7 +1,7 @@
 """GPU box: build time and traversal cost of the GPU-built (LBVH) stream vs the host-built SAH stream."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from raytracedshadows_amd import api, workloads
 import oracle
