@@ -224,12 +224,10 @@ def loop_leaf(form):
          "s_cmp_lg_u32 s43, -1",
          "s_cbranch_scc1 9f"]
     L += test
-    L += [f"s_andn2_b64 s[50:51], %[m0], {r}",
+    L += [f"s_andn2_b64 s[50:51], %[m0], {r}",            # members whose own test failed: they leave the packet ...
           "s_cbranch_scc0 5b",
-          "s_mov_b64 s[48:49], exec",
-          "s_mov_b64 exec, s[50:51]",
-          "v_mov_b32 %[w0], s47",
-          "s_mov_b64 exec, s[48:49]",
+          "v_mov_b32 %[t0], s47",
+          "v_cndmask_b32_e64 %[w0], %[w0], %[t0], s[50:51]",   # ... and wait on the miss link
           f"s_and_b64 %[m0], %[m0], {r}",
           "s_cbranch_scc1 5b",
           "4:",                                           # side-step to s47
