@@ -166,6 +166,20 @@ def test_generic_rays_including_nan_inf_and_axis_parallel(ctx):
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, f"kernel {v}: {bad.size} of {n} rays differ, first {bad[:5]}"
     assert 0 < want.sum() < n
+    # device-pointer entry, default variant (generic rays: lane-per-ray with work sharing)
+    ctx.set_option("kernel", -1)
+    d_rays, d_out = ctx.malloc(rays.nbytes), ctx.malloc(n)
+    try:
+        ctx.h2d(d_rays, rays)
+        ctx.trace_rays_device(d_rays, n, d_out)
+        ctx.synchronize()
+        got = np.zeros(n, np.uint8)
+        ctx.d2h(got, d_out)
+        assert (got == want).all()
+        assert ctx.last_kernel_name() == "traceRaysKernel<7>"
+    finally:
+        ctx.free(d_rays)
+        ctx.free(d_out)
 
 
 def test_degenerate_and_denormal_triangles(ctx):
