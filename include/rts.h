@@ -182,6 +182,8 @@ const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
 /* Dispatch order of the image tiles for traces whose workgroup count equals `count`: workgroup i works on tile
  * order[i] (a permutation of 0..count-1; NULL or 0 restores the natural order).  Speed only. */
 int rts_ctx_set_tile_order(rts_ctx* ctx, const uint32_t* order, size_t count);
+/* Free and total device memory in bytes (hipMemGetInfo on the context's device); either pointer may be NULL. */
+int rts_device_mem_info(rts_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Diagnostics (tools/wave_stats.py): after rts_ctx_set_option(ctx, "wave_stats", n_waves) the packet
  * kernels record 4 x u64 per wave: start clock, end clock, {dissolved flag (bit 0) | lane-per-ray iterations after the
  * dissolve (bits 8-31) | clocks from start to the dissolve (32-63)}, {tile x (48-63) | tile y (32-47) | lane-steps in

@@ -139,6 +139,7 @@ _sig("rts_timer_elapsed_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
 _sig("rts_ctx_set_tile_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_device_mem_info", C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
      C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
 _sig("rtsh_primary_gbuffer", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
@@ -319,6 +320,12 @@ class ShadowContext:
 
     def d2h(self, array, dptr):
         _check(_lib.rts_memcpy_d2h(self._h, _ptr(array), C.c_void_p(dptr), array.nbytes), "rts_memcpy_d2h")
+
+    def mem_info(self):
+        """(free, total) device memory in bytes."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        _check(_lib.rts_device_mem_info(self._h, C.byref(f), C.byref(t)), "rts_device_mem_info")
+        return f.value, t.value
 
     def synchronize(self, stream=None):
         _check(_lib.rts_stream_synchronize(self._h, C.c_void_p(stream or 0)), "rts_stream_synchronize")

@@ -366,6 +366,15 @@ int rts_memcpy_d2h(rts_ctx* c, void* d, const void* s, size_t bytes) {
     RTS_HIP(hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost));
     return RTS_OK;
 }
+int rts_device_mem_info(rts_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    RTS_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return RTS_OK;
+}
 int rts_stream_synchronize(rts_ctx* c, void* stream) {
     if (!c) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));

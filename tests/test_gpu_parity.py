@@ -289,6 +289,36 @@ def test_error_behaviour(ctx):
         fresh.close()
 
 
+def test_contexts_and_uploads_do_not_leak_device_memory(ctx):
+    """Create/destroy contexts and re-upload streams of different sizes (host builder and device builder, host-pointer
+    traces that grow the staging buffers): the device's free memory returns to where it was."""
+    small, big = scenes.terrain(8), scenes.terrain(96)
+    blobs = []
+    for sc in (small, big):
+        verts, idx = sc.flat()
+        blobs.append((verts, idx, sc.triangle_count, api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes))
+    k = api.RayTracingConstants.make([0, 50, 0], [0.3, 0.8, 0.5], 64, 64)
+    pos = np.zeros((64, 64, 4), np.float32)
+
+    def cycle():
+        with api.ShadowContext(0) as c:
+            for verts, idx, P, packed in blobs + blobs[::-1]:
+                c.set_bvh(packed)
+                c.trace_shadow_mask(k, pos, 64, 64)
+                api.bvh_build_device(c, verts, 8, idx, P, install=True, want_packed=False)
+                c.trace_shadow_mask(k, pos, 64, 64)
+            c.set_option("wave_stats", 64)
+            c.set_tile_order(np.arange(64, dtype=np.uint32))
+    cycle()                                                  # first use may grow allocator pools / hipcub temporaries
+    ctx.synchronize()
+    before = ctx.mem_info()[0]
+    for _ in range(5):
+        cycle()
+    ctx.synchronize()
+    after = ctx.mem_info()[0]
+    assert before - after < (8 << 20), f"device memory shrank by {(before - after) >> 20} MiB over 5 context cycles"
+
+
 def test_tuning_options_never_change_the_mask(ctx):
     """Packet size, dissolve window/threshold (16 = always dissolve -> every ray finishes lane-per-ray from the
     node it stands or waits on; 0 = never), workgroup shape and block order are speed knobs only."""
