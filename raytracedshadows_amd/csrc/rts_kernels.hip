@@ -111,7 +111,9 @@ __device__ __forceinline__ Ray makeShadowRay(const TraceParams& p, F3 rel, uint3
 
 // True when the FAST slab test is provably identical to the EXACT one for this ray.
 __device__ __forceinline__ bool raySafe(const Ray& r) {
-    return finite3(r.o) && finite3(r.inv) && r.inv.x != 0.0f && r.inv.y != 0.0f && r.inv.z != 0.0f;
+    // v_cmp_class masks: 0x1F8 = any finite value, 0x198 = finite and not zero (+-normal, +-denormal)
+    return __builtin_amdgcn_classf(r.o.x, 0x1F8) && __builtin_amdgcn_classf(r.o.y, 0x1F8) && __builtin_amdgcn_classf(r.o.z, 0x1F8) &&
+           __builtin_amdgcn_classf(r.inv.x, 0x198) && __builtin_amdgcn_classf(r.inv.y, 0x198) && __builtin_amdgcn_classf(r.inv.z, 0x198);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,25 +427,22 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
         for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], 0u, lds);
         return;
     }
-    // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test
+    // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test.  (1/d is finite and non-zero for
+    // every live ray here, so "negative" is the sign bit: three shifts per ray instead of three compares + ballots.)
     uint32_t form = 8;
     if (p.bvhOrdered) {
-        bool uniform = true;
-        uint32_t octant = 0;
+        uint32_t first = 0;
+        uint64_t differs = 0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            uint64_t neg = 0, pos = 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float v = a == 0 ? r[k].inv.x : (a == 1 ? r[k].inv.y : r[k].inv.z);
-                const uint64_t n = __builtin_amdgcn_ballot_w64(v < 0.0f) & members[k];
-                neg |= n;
-                pos |= members[k] & ~n;
-            }
-            uniform = uniform && (neg == 0 || pos == 0);
-            octant |= neg ? (1u << a) : 0u;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t oct = (__float_as_uint(r[k].inv.x) >> 31) | ((__float_as_uint(r[k].inv.y) >> 31) << 1) |
+                                 ((__float_as_uint(r[k].inv.z) >> 31) << 2);
+            if (k == 0) first = (uint32_t)__builtin_amdgcn_readlane((int)oct, __builtin_ctzll(any));   // `any` != 0 here ...
+            differs |= __builtin_amdgcn_ballot_w64(oct != first) & members[k];
         }
-        if (uniform) form = octant;
+        // ... but its lowest lane need not be live in set 0 when K > 1: then `first` may belong to a dead ray, which only
+        // costs the uniform form (a wrong `first` never matches every live ray unless it is their common pattern)
+        if (differs == 0 && (K == 1 || (members[0] >> __builtin_ctzll(any)) & 1ull)) form = first;
     }
     form = (uint32_t)__builtin_amdgcn_readfirstlane((int)form);
     // Dissolve rule (evaluated inside the asm loop).  A packet step serves the rays standing on `cur`; a
@@ -624,14 +623,16 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // WPB = waves per block: 4 (block = 2x2 wave tiles) or 1 (block = one wave tile, so that a finished wave
 // frees its slot without waiting for three siblings).
 // SOFT = more than one sample per pixel: only then the G-buffer position has to stay in registers across the walk.
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false>
+// PLAIN = the everyday launch (natural tile order on a 2-D grid, one contiguous row range, no diagnostics): the scalar
+// prologue that sorts out the other cases is compiled away.
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
-    uint32_t bx, by;
-    if (!blockToXY(p, blockIdx.x, &bx, &by)) return;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);
     const uint32_t v0 = (WPB == 4 ? by * (2u * TH) + (wave >> 1) * TH : by * TH) + (lane >> 3);
@@ -640,7 +641,8 @@ void shadowMaskPacketKernel(TraceParams p) {
     F3 rel[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t x = x0 + (k & 1) * 8u, y = ownedRow(p, v0 + (k >> 1) * 8u);
+        const uint32_t x = x0 + (k & 1) * 8u;
+        const uint32_t y = PLAIN ? p.rowBegin + v0 + (k >> 1) * 8u : ownedRow(p, v0 + (k >> 1) * 8u);
         live[k] = (x < p.W) && (y < p.rowEnd);
         pix[k] = (size_t)y * p.W + x;
         rel[k] = F3{ 0.f, 0.f, 0.f };
@@ -651,10 +653,10 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
     const NodeStream bvh = openStream(p);
     const uint32_t ns = SOFT ? p.nsamples : 1u;
-    const uint64_t tStart = p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
+    const uint64_t tStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
     int32_t left = 0;
     ShareDiag shareDiag;
-    shareDiag.on = p.waveStats != nullptr;
+    shareDiag.on = !PLAIN && p.waveStats != nullptr;
     uint32_t lit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lit[k] = 0;
@@ -672,7 +674,7 @@ void shadowMaskPacketKernel(TraceParams p) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);       // comp:150
-    if (p.waveStats && lane == 0) {              // diagnostics: never read by any kernel, never part of an output
+    if (!PLAIN && p.waveStats && lane == 0) {    // diagnostics: never read by any kernel, never part of an output
         uint64_t* o = p.waveStats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave) * 4;
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
@@ -746,7 +748,12 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
-        case V_PACKET: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p); break;
+        case V_PACKET:
+            if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
+            else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
+            else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);
+            break;
         case V_PACKET2: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1, false, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<2, 1, false, false>), grid, b1, 0, stream, p); break;
         case V_PACKET4: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1, false, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<4, 1, false, false>), grid, b1, 0, stream, p); break;
         case V_PACKET_PF: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true, true>), grid, b1, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, true, false>), grid, b1, 0, stream, p); break;
