@@ -127,7 +127,7 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *   "kernel"        -1 = auto (default: packet kernel for >= 256 K pixels, variant 7 below); 0 straight,
  *                   1 while-while, 2 postpone, 3 packet (8x8 px / wave), 4 packet2 (16x8), 5 packet4 (16x16),
  *                   6 packet + successor prefetch, 7 lane-per-ray with work sharing.  get "kernel_count" = 8.
- *   "packet_budget" side-steps between two coherence checks of a packet (default 8)
+ *   "packet_budget" side-steps between two coherence checks of a packet (default 16)
  *   "packet_share"  a packet dissolves when it picks up fewer than share/16 of its live rays per side-step (default 4)
  *   "block_waves"   waves per workgroup of the packet kernels: 1 (default) or 4
  *   "xcd_swizzle"   1 = contiguous image chunk per XCD (default 0: measured slower)

@@ -26,7 +26,7 @@ struct rts_ctx {
     void* d_in = nullptr; size_t inBytes = 0;
     void* d_out = nullptr; size_t outBytes = 0;
     const char* lastKernel = "";
-    int packetBudget = 8;
+    int packetBudget = 16;
     int packetShare = 4;
     int blockWaves = 1;
     int ldsPad = 0;              // experiment knob: dynamic LDS bytes per workgroup (throttles occupancy)

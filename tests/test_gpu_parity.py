@@ -507,6 +507,6 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                 assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
     finally:
         ctx.set_option("kernel", -1)
-        ctx.set_option("packet_budget", 8)
+        ctx.set_option("packet_budget", 16)
         ctx.set_option("packet_share", 4)
         ctx.set_option("block_waves", 1)
