@@ -529,3 +529,81 @@ extern "C" void orc_tile_union_stats_wh(const uint32_t* packed, const float* con
     }
     out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = sumLeafU; out[5] = 0;
 }
+
+// Experiment only: how many nodes would be visited if the children of an inner node were walked in another
+// order?  mode 0 = the reference's (left = larger surface area first); 1 = the child whose box centre comes first along
+// the ray on the axis where the two centres differ most; 2 = the child whose box the ray enters first (exact entry
+// distances).  The mask does not depend on the order (any-hit is an OR over the reachable triangles); the visit counts do.
+// out: tiles, sum of per-tile union sizes, sum of per-tile longest ray, sum of visits over all rays, occluded rays.
+extern "C" void orc_order_experiment(const uint32_t* packed, const float* constants, const void* light_v,
+                                     const float* positions, uint32_t W, uint32_t H, int mode, uint64_t* out) {
+    const OLight& lt = *(const OLight*)light_v;
+    uint64_t tiles = 0, sumU = 0, sumM = 0, sumV = 0, occl = 0;
+    const uint32_t TW = 8, TH = 8, tx = W / TW, ty = H / TH;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : tiles, sumU, sumM, sumV, occl)
+#endif
+    for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
+        uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
+        std::vector<u32> visited;
+        u32 maxV = 0;
+        for (u32 l = 0; l < TW * TH; ++l) {
+            u32 x = bx * TW + (l % TW), y = by * TH + (l / TW);
+            size_t pix = (size_t)y * W + x;
+            V3 rel = { positions[pix * 4 + 0], positions[pix * 4 + 1], positions[pix * 4 + 2] };
+            V3 o, d; float tmax;
+            genRay(constants, rel, lt, 0, &o, &tmax, &d);
+            V3 invdir = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+            u32 stack[128]; int sp = 0; stack[sp++] = 0;
+            u32 v = 0; bool hit = false;
+            while (sp > 0 && !hit) {
+                const u32 node = stack[--sp];
+                const u32* a = packed + (size_t)node * 8; const u32* b = a + 4;
+                ++v; visited.push_back(node);
+                if (a[3] != kInvalid) {
+                    const u32* tt = packed + (size_t)a[3] * 4;
+                    V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+                    V3 v0 = { u2f(tt[0]), u2f(tt[1]), u2f(tt[2]) };
+                    hit = rayTri(o, tmax, d, v0, e0, e1);
+                    continue;
+                }
+                V3 pmin = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, pmax = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+                if (!rayBox(o, invdir, pmin, pmax)) continue;
+                const u32 left = node + 1, right = packed[(size_t)left * 8 + 7];
+                bool leftFirst = true;
+                if (mode != 0) {
+                    const u32* la = packed + (size_t)left * 8; const u32* ra = packed + (size_t)right * 8;
+                    const bool lLeaf = la[3] != kInvalid, rLeaf = ra[3] != kInvalid;
+                    if (!lLeaf && !rLeaf) {
+                        float lc[3], rc[3], lmin[3], rmin[3], lmax[3], rmax[3];
+                        for (int k = 0; k < 3; ++k) {
+                            lmin[k] = u2f(la[k]); lmax[k] = u2f(la[4 + k]); rmin[k] = u2f(ra[k]); rmax[k] = u2f(ra[4 + k]);
+                            lc[k] = 0.5f * (lmin[k] + lmax[k]); rc[k] = 0.5f * (rmin[k] + rmax[k]);
+                        }
+                        const float dd[3] = { d.x, d.y, d.z }, oo[3] = { o.x, o.y, o.z }, ii[3] = { invdir.x, invdir.y, invdir.z };
+                        if (mode == 1) {
+                            int ax = 0; float best = -1.f;
+                            for (int k = 0; k < 3; ++k) { float s = std::fabs(lc[k] - rc[k]); if (s > best) { best = s; ax = k; } }
+                            leftFirst = (lc[ax] - rc[ax]) * dd[ax] <= 0.f;        // left centre comes first along the ray
+                        } else {
+                            float tl = 0.f, tr = 0.f;
+                            for (int k = 0; k < 3; ++k) {
+                                float l0 = (lmin[k] - oo[k]) * ii[k], l1 = (lmax[k] - oo[k]) * ii[k];
+                                float r0 = (rmin[k] - oo[k]) * ii[k], r1 = (rmax[k] - oo[k]) * ii[k];
+                                tl = std::max(tl, std::min(l0, l1)); tr = std::max(tr, std::min(r0, r1));
+                            }
+                            leftFirst = tl <= tr;
+                        }
+                    }
+                }
+                if (sp + 2 > 128) break;
+                if (leftFirst) { stack[sp++] = right; stack[sp++] = left; } else { stack[sp++] = left; stack[sp++] = right; }
+            }
+            sumV += v; if (v > maxV) maxV = v; occl += hit ? 1 : 0;
+        }
+        std::sort(visited.begin(), visited.end());
+        visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
+        sumU += visited.size(); sumM += maxV; ++tiles;
+    }
+    out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = occl;
+}

@@ -156,3 +156,15 @@ def ray_tri(o4, d3, v0, e0, e1):
 
 def epsilon_for(f, diff=13):
     return np.float32(_o.orc_epsilon_for(np.float32(f), diff))
+
+
+def order_experiment(packed, constants_array, light, positions, W, H, mode):
+    """Visit statistics under another child order (experiment, see orc_order_experiment): dict of per-ray / per-tile means."""
+    packed = np.ascontiguousarray(packed, np.uint32)
+    k = np.ascontiguousarray(constants_array, np.float32)
+    positions = np.ascontiguousarray(positions, np.float32)
+    out = np.zeros(8, np.uint64)
+    _o.orc_order_experiment(_p(packed), _p(k), C.byref(light), _p(positions), W, H, mode, _p(out))
+    tiles = int(out[0])
+    return {"tiles": tiles, "union_per_tile": int(out[1]) / tiles, "longest_per_tile": int(out[2]) / tiles,
+            "visits_per_ray": int(out[3]) / (tiles * 64), "occluded": int(out[4])}
