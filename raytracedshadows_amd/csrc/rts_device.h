@@ -15,7 +15,7 @@ enum Variant {
     V_PACKET_PF = 6,   // V_PACKET with the sequential successor node prefetched into a second SGPR set
     V_SHARE = 7,       // lane-per-ray with work sharing inside the wave (idle lanes take half of a busy ray's range)
     V_COUNT,
-    V_AUTO = -1        // packet for big launches, straight for small ones
+    V_AUTO = -1        // packet for big launches, V_SHARE for small ones and for generic rays
 };
 
 // Kernel argument block (passed by value; lives in the kernarg segment, read with scalar loads).
