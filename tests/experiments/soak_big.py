@@ -1,0 +1,60 @@
+"""Soak (GPU box): random large frames (packet kernels at full occupancy) on terrain / atrium / cornell scenes with random
+cameras, lights, sample counts, tuning knobs and stripe layouts, each mask against the oracle, for a fixed time."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from raytracedshadows_amd import api, scenes, workloads
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+t0 = time.time()
+cases = 0
+with api.ShadowContext(0) as ctx:
+    while time.time() - t0 < budget:
+        kind = rs.randint(0, 3)
+        sc = scenes.terrain(int(rs.choice([40, 90, 160]))) if kind == 0 else (scenes.cornell() if kind == 1 else scenes.SCENES["atrium"]())
+        verts, idx = sc.flat()
+        packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes
+        lo, hi = sc.bbox_min, sc.bbox_max
+        W, H = int(rs.randint(520, 1500)), int(rs.randint(500, 900))
+        eye = (hi + (hi - lo) * rs.random_sample(3) * 0.5 + 1).astype(np.float32)
+        target = (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32)
+        pos, _ = api.primary_positions(packed, eye, target, 1.0, W, H)
+        k = api.RayTracingConstants.make(eye, [0.3, 0.8, 0.5], W, H)
+        spp = int(rs.choice([1, 1, 1, 3, 16]))
+        where = (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32) if rs.rand() < 0.5 else (hi + 5).astype(np.float32)
+        light = api.Light.make(api.Light.POINT, where, scenes.jitter_offsets(spp, 0.5, cases) if spp > 1 else None) if rs.rand() < 0.8 else None
+        want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(light, k), pos, W, H)
+        ctx.set_bvh(packed)
+        d_pos, d_mask = ctx.malloc(pos.nbytes), ctx.malloc(W * H)
+        ctx.h2d(d_pos, pos)
+        try:
+            for kernel in (-1, 3, 4, 5, 6, 7):
+                ctx.set_option("kernel", kernel)
+                ctx.set_option("packet_budget", int(rs.choice([1, 4, 16, 40])))
+                ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
+                ctx.set_option("block_waves", int(rs.choice([1, 4])))
+                ctx.set_option("xcd_swizzle", int(rs.randint(0, 2)))
+                got = np.full((H, W), 7, np.uint8)
+                ctx.h2d(d_mask, got)
+                n = int(rs.choice([1, 1, 2, 3, 5]))
+                if n == 1:
+                    ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)
+                else:
+                    band = 32 * int(rs.choice([1, 2]))
+                    for s in range(n):
+                        ctx.trace_shadow_mask_stripes_device(k, d_pos, W, H, d_mask, band, n, s, light=light)
+                ctx.synchronize()
+                ctx.d2h(got, d_mask)
+                bad = int((got != want).sum())
+                assert bad == 0, (cases, sc.name, W, H, kernel, spp, n, bad)
+        finally:
+            ctx.free(d_pos); ctx.free(d_mask)
+            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0)):
+                ctx.set_option(key, v)
+        cases += 1
+        if cases % 5 == 0:
+            print(f"{cases} big cases ok ({time.time() - t0:.0f}s)", flush=True)
+print(f"soak_big: {cases} random large frames x 6 kernels (random knobs, stripes, 1-16 samples) all bit-exact ({time.time() - t0:.0f}s)")
