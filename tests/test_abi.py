@@ -76,3 +76,24 @@ def test_generated_asm_include_is_up_to_date(tmp_path):
     finally:
         sys.argv = argv
     assert open(gen.OUT).read() == committed
+
+
+def test_plain_c_program_drives_the_host_producer(tmp_path):
+    """include/*.h compile as C99 and a C program gets the Appendix-A stream out of librts.so (no GPU call)."""
+    import json
+    import struct
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(api.lib_path())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lrts",
+                    "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    words = [int(w, 16) for w in out]
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "appendix_a_4tri.json")))["packed"]
+    assert len(words) == 4 * len(gold)
+    for i, (xyz, w) in enumerate(gold):
+        got = struct.unpack("<3f", struct.pack("<3I", *words[4 * i:4 * i + 3]))
+        assert list(got) == [float(v) for v in xyz], (i, got, xyz)
+        if w is not None:
+            assert words[4 * i + 3] == int(w, 16), (i, hex(words[4 * i + 3]), w)
