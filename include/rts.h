@@ -28,6 +28,8 @@ enum {
     RTS_ERR_NONFINITE   = 3, /* NaN/Inf vertex (reference: unbounded recursion, SURVEY E-4) */
     RTS_ERR_NO_BVH      = 4, /* trace called before rts_ctx_set_bvh                         */
     RTS_ERR_BAD_BVH     = 5, /* packed buffer fails structural validation                   */
+    RTS_ERR_DEGENERATE  = 6, /* finite vertices whose extents overflow the SAH cost to +inf: no split position
+                                exists (reference: unbounded recursion, SURVEY E-4/E-5)      */
     RTS_ERR_HIP         = 100 /* 100 + hipError_t                                           */
 };
 const char* rts_status_string(int status);

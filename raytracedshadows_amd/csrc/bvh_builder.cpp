@@ -50,6 +50,7 @@ struct Build {
     std::condition_variable cv;
     std::deque<Range> queue;
     std::atomic<long> pending{0};
+    std::atomic<bool> degenerate{false};   // some range had no split position (every SAH cost overflowed)
 };
 
 struct Scratch {
@@ -173,6 +174,10 @@ void worker(Build* bp, bool shareWork) {
             float lo[3], hi[3];
             rangeBounds(b, cur.begin, cur.end, lo, hi);                                // cpp:190
             u32 mid = chooseSplit(b, s, cur.begin, cur.end, lo, hi);                   // cpp:192
+            // Extents around 1e19 and beyond overflow the surface areas to +inf: no cost is < FLT_MAX, the split stays
+            // at `begin` and the reference recurses without bound on an empty range.  Here the
+            // range is abandoned and build() reports RTS_ERR_DEGENERATE; nothing is written for it.
+            if (mid <= cur.begin || mid >= cur.end) { b.degenerate.store(true); continue; }
             u32 id = mid - 1;
             Inner& in = b.inner[id];
             for (int k = 0; k < 3; ++k) { in.lo[k] = lo[k]; in.hi[k] = hi[k]; }
@@ -250,6 +255,7 @@ bool BVHBuilder::build(const float* vertices, u32 stride, const u32* indices, u3
         for (int t = 0; t < nt; ++t) pool.emplace_back(worker, &b, true);
         for (auto& t : pool) t.join();
     }
+    if (b.degenerate.load()) { lastError = RTS_ERR_DEGENERATE; return false; }
 
     // Larger-surface-area child first (cpp:202-208): strict `>` on the right child.
     auto refBox = [&](u32 ref, const float*& lo, const float*& hi) {

@@ -73,6 +73,7 @@ const char* rts_status_string(int s) {
     case RTS_ERR_NONFINITE: return "non-finite vertex";
     case RTS_ERR_NO_BVH: return "no BVH set on context";
     case RTS_ERR_BAD_BVH: return "packed BVH failed validation";
+    case RTS_ERR_DEGENERATE: return "SAH cost overflow: no split position (coordinate extents too large)";
     default: break;
     }
     if (s >= RTS_ERR_HIP) return hipGetErrorString((hipError_t)(s - RTS_ERR_HIP));
@@ -187,7 +188,8 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!c || !key) return RTS_ERR_INVALID_ARG;
     if (!strcmp(key, "kernel")) { if (value < rts::V_AUTO || value >= rts::V_COUNT) return RTS_ERR_INVALID_ARG; c->variant = value; return RTS_OK; }
     if (!strcmp(key, "xcd_swizzle")) { c->swizzle = value ? 1 : 0; return RTS_OK; }
-    if (!strcmp(key, "packet_budget")) { if (value < 1) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
+    // (1..4096: the dissolve rule multiplies budget * share * live rays in 32 bits)
+    if (!strcmp(key, "packet_budget")) { if (value < 1 || value > 4096) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }

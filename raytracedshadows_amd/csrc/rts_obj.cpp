@@ -38,7 +38,9 @@ float readNumber(const char* s, const char** end) {
         int esign = 1;
         if (*s == '-') { esign = -1; ++s; } else if (*s == '+') ++s;
         int e = 0;
-        for (; isDigit(*s); ++s) e = e * 10 + (*s - '0');
+        // (saturated: the reference accumulates in an int with no limit, which is undefined behaviour beyond 2^31;
+        //  any |exponent| >= 100000 gives the same 0 / inf as a larger one)
+        for (; isDigit(*s); ++s) if (e < 100000) e = e * 10 + (*s - '0');
         p10 += esign * e;
     }
     *end = s;
@@ -53,7 +55,7 @@ int readInt(const char* s, const char** end) {
     bool neg = (*s == '-');
     if (*s == '-' || *s == '+') ++s;
     unsigned v = 0;
-    for (; isDigit(*s); ++s) v = v * 10 + (unsigned)(*s - '0');
+    for (; isDigit(*s); ++s) if (v < 0x0CCCCCCCu) v = v * 10 + (unsigned)(*s - '0');   // saturates below 2^31
     *end = s;
     return neg ? -(int)v : (int)v;
 }
@@ -144,8 +146,13 @@ extern "C" int rtsh_obj_load(const char* path, float* vertices, size_t cap, uint
                              float bbox_min[3], float bbox_max[3]) {
     if (!path || !vertex_count) return RTS_ERR_INVALID_ARG;
     Mesh m;
-    if (!parseFile(path, m) || !validate(m)) return RTS_ERR_INVALID_ARG;
+    try {                                            // bad_alloc / length_error must not cross the C ABI
+        if (!parseFile(path, m) || !validate(m)) return RTS_ERR_INVALID_ARG;
+    } catch (...) {
+        return RTS_ERR_CAPACITY;
+    }
     const size_t nverts = m.corners.size();
+    if (nverts > 0xFFFFFFFFull) return RTS_ERR_CAPACITY;
     *vertex_count = (uint32_t)nverts;
     if (!vertices) return RTS_OK;
     if (cap < nverts) return RTS_ERR_CAPACITY;

@@ -1,11 +1,12 @@
 """Row-stripe partition of a frame over GPUs: no exchange, disjoint output."""
 
 
-def stripe_rows(height, n_ranks, rank, band=16, interleaved=True):
+def stripe_rows(height, n_ranks, rank, band=32, interleaved=True):
     """Row ranges [(begin, end), ...] owned by `rank`.
 
     interleaved: bands of `band` rows dealt round-robin (balances sky vs geometry);
-    otherwise one contiguous block of rows per rank, rounded to `band`.
+    otherwise one contiguous block of rows per rank, rounded to `band`.  The default band (32) is what
+    rts_trace_shadow_mask_stripes_device accepts (a multiple of 32 rows).
     """
     if n_ranks < 1 or not 0 <= rank < n_ranks or band < 1:
         raise ValueError("bad stripe arguments")

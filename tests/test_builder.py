@@ -147,3 +147,39 @@ def test_validate_rejects_broken_buffers():
 def _set(p, row, col, val):
     p[row, col] = val
     return p
+
+
+def test_extents_that_overflow_the_sah_cost_return_a_status():
+    """Finite vertices around 1e19 and beyond: every surface area is +inf, no cost is < FLT_MAX, the reference's split
+    stays at `begin` and it recurses without bound.  The product reports RTS_ERR_DEGENERATE."""
+    rs = np.random.RandomState(3)
+    for scale in (1e20, 1e30, 3e38):
+        for P in (3, 64, 9000):
+            v = ((rs.random_sample((3 * P, 3)) - 0.5) * scale).astype(np.float32)
+            with pytest.raises(api.RtsError) as e:
+                api.BVHBuilder().build(v, 3, np.arange(3 * P, dtype=np.uint32), P)
+            assert e.value.status == 6
+    v = ((rs.random_sample((30, 3)) - 0.5) * 1e18).astype(np.float32)          # large but still finite costs: fine
+    assert api.bvh_validate(api.BVHBuilder().build(v, 3, np.arange(30, dtype=np.uint32), 10).m_packedNodes) == 10
+
+
+def test_builder_under_address_and_ub_sanitizers(tmp_path):
+    """The host producer compiled with -fsanitize=address,undefined (CPU build only) over huge extents, cost ties and
+    mixed scales, single- and multi-threaded: no wild write, a status for every input (tests/cpp/builder_asan.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "builder_asan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-pthread", os.path.join(root, "tests", "cpp", "builder_asan.cpp"),
+                    os.path.join(root, "raytracedshadows_amd", "csrc", "bvh_builder.cpp"), "-o", exe], check=True)
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr[-2000:]
+    rows = [l.split() for l in run.stdout.splitlines()]
+    assert len(rows) >= 50
+    for name, status, count in rows:
+        assert status in ("0", "6"), (name, status)
+        if name.startswith(("scale1e+20", "scale1e+30", "scale3e+38")) or name == "one_huge":
+            assert status == "6", name
+        if status == "0":
+            assert int(count) >= 3
