@@ -449,6 +449,126 @@ void orc_brute_force_rays(const uint32_t* packed, uint32_t P, const float* rays,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// G-buffer oracle: what the harness's closest-hit pass must produce for the position target the
+// shadow kernel reads, i.e. Source/Shaders/Model.frag:35-39 `outCameraRelativePosition = v_worldPos - g_cameraPosition`
+// with the background left at the clear value 0.  For a ray-traced G-buffer the camera-relative
+// world position of the visible surface is d * t.  Written independently of the product's stackless walk
+// (rts_closest_hit.h): an explicit-stack descent that finds the children through the layout (left = i + 1,
+// right = next(left)).  Contract shared with the harness, stated here once:
+//   primary ray   o = eye, d = fwd + right*sx + up*sy (un-normalised), sx/sy from the pixel centre
+//   triangle      Moeller-Trumbore as comp:41-59, but accepted only if det != 0, b1 >= 0, b2 >= 0, b1+b2 <= 1,
+//                 0 < t < best (strict: of equal distances the triangle met first in DFS order wins)
+//   box           slab interval per axis clipped to [0, best]; NaN slabs (0*inf) are ignored; entered iff t1 >= t0
+//   camera        lookAt(eye -> target), +Y up, vertical fov (RayTracedShadows.cpp:238-242)
+// `cull` = 0 switches the box test off (brute force over every triangle in DFS order): the independent check of
+// the traversal itself on small scenes.
+// ---------------------------------------------------------------------------------------------
+struct OCamera { V3 eye, fwd, right, up; float tanHalf, aspect; };
+
+static OCamera lookAt(const float* eye, const float* target, float fovy, u32 W, u32 H) {
+    OCamera c;
+    c.eye = V3{ eye[0], eye[1], eye[2] };
+    V3 f = subv(V3{ target[0], target[1], target[2] }, c.eye);
+    float fl = sqrtf(dotv(f, f));
+    if (fl > 0) { float s = 1.0f / fl; c.fwd = V3{ f.x * s, f.y * s, f.z * s }; } else c.fwd = V3{ 0, 0, -1 };
+    V3 up0 = { 0, 1, 0 };
+    V3 r = { up0.y * c.fwd.z - up0.z * c.fwd.y, up0.z * c.fwd.x - up0.x * c.fwd.z, up0.x * c.fwd.y - up0.y * c.fwd.x };
+    float rl = sqrtf(dotv(r, r));
+    if (rl > 0) { float s = 1.0f / rl; c.right = V3{ r.x * s, r.y * s, r.z * s }; } else c.right = V3{ 1, 0, 0 };
+    c.up = V3{ c.fwd.y * c.right.z - c.fwd.z * c.right.y, c.fwd.z * c.right.x - c.fwd.x * c.right.z,
+               c.fwd.x * c.right.y - c.fwd.y * c.right.x };
+    c.tanHalf = tanf(fovy * 0.5f);
+    c.aspect = (float)W / (float)H;
+    return c;
+}
+
+static bool nearestHit(const u32* bvh, V3 o, V3 d, int cull, float* tOut, u32* leafOut) {
+    const float inf = u2f(0x7F800000u);
+    const float oo[3] = { o.x, o.y, o.z };
+    const float inv[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    float best = inf; u32 bestLeaf = kInvalid;
+    std::vector<u32> todo;
+    todo.push_back(0);
+    while (!todo.empty()) {
+        const u32 i = todo.back(); todo.pop_back();
+        const u32* a = bvh + (size_t)i * 8; const u32* b = a + 4;
+        if (a[3] != kInvalid) {
+            const u32* tv = bvh + (size_t)a[3] * 4;
+            V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(b[0]), u2f(b[1]), u2f(b[2]) };
+            V3 v0 = { u2f(tv[0]), u2f(tv[1]), u2f(tv[2]) };
+            V3 s1 = { d.y * e1.z - d.z * e1.y, d.z * e1.x - d.x * e1.z, d.x * e1.y - d.y * e1.x };
+            float det = s1.x * e0.x + s1.y * e0.y + s1.z * e0.z;
+            if (det != 0.0f) {
+                float invd = 1.0f / det;
+                V3 dd = subv(o, v0);
+                float b1 = (dd.x * s1.x + dd.y * s1.y + dd.z * s1.z) * invd;
+                V3 s2 = { dd.y * e0.z - dd.z * e0.y, dd.z * e0.x - dd.x * e0.z, dd.x * e0.y - dd.y * e0.x };
+                float b2 = (d.x * s2.x + d.y * s2.y + d.z * s2.z) * invd;
+                float t = (e1.x * s2.x + e1.y * s2.y + e1.z * s2.z) * invd;
+                if (b1 >= 0.0f && b2 >= 0.0f && b1 + b2 <= 1.0f && t > 0.0f && t < best) { best = t; bestLeaf = i; }
+            }
+            continue;
+        }
+        bool enter = true;
+        if (cull) {
+            float t0 = 0.0f, t1 = best;
+            for (int k = 0; k < 3; ++k) {
+                float f = (u2f(b[k]) - oo[k]) * inv[k], n = (u2f(a[k]) - oo[k]) * inv[k];
+                float far_ = f > n ? f : n, near_ = f > n ? n : f;
+                if (far_ < t1) t1 = far_;
+                if (near_ > t0) t0 = near_;
+            }
+            enter = t1 >= t0;
+        }
+        if (enter) {
+            const u32 left = i + 1, right = bvh[(size_t)left * 8 + 7];      // the left child's miss link IS the right child
+            todo.push_back(right);
+            todo.push_back(left);                                           // popped first: DFS order
+        }
+    }
+    *tOut = best; *leafOut = bestLeaf;
+    return bestLeaf != kInvalid;
+}
+
+void orc_primary_gbuffer(const uint32_t* packed, const float* eye, const float* target, float fovy, uint32_t W,
+                         uint32_t H, int cull, float* positions, float* normals, uint64_t* hits, int threads) {
+    const OCamera c = lookAt(eye, target, fovy, W, H);
+    uint64_t count = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : count)
+#endif
+    for (int64_t y = 0; y < (int64_t)H; ++y) {
+        for (u32 x = 0; x < W; ++x) {
+            float sx = (((float)x + 0.5f) / (float)W * 2.0f - 1.0f) * c.tanHalf * c.aspect;
+            float sy = (1.0f - ((float)y + 0.5f) / (float)H * 2.0f) * c.tanHalf;
+            V3 d = { c.fwd.x + c.right.x * sx + c.up.x * sy, c.fwd.y + c.right.y * sx + c.up.y * sy,
+                     c.fwd.z + c.right.z * sx + c.up.z * sy };
+            float* p = positions + ((size_t)y * W + x) * 4;
+            float* nn = normals ? normals + ((size_t)y * W + x) * 4 : nullptr;
+            float t; u32 leaf;
+            if (!nearestHit(packed, c.eye, d, cull, &t, &leaf)) {
+                p[0] = p[1] = p[2] = p[3] = 0.0f;                           // clear value: background
+                if (nn) nn[0] = nn[1] = nn[2] = nn[3] = 0.0f;
+                continue;
+            }
+            ++count;
+            p[0] = d.x * t; p[1] = d.y * t; p[2] = d.z * t; p[3] = 1.0f;    // Model.frag:35  worldPos - cameraPos
+            if (nn) {                                                       // Model.frag:33,38: unit normal facing the viewer
+                const u32* a = packed + (size_t)leaf * 8;
+                V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(a[4]), u2f(a[5]), u2f(a[6]) };
+                V3 n = { e0.y * e1.z - e0.z * e1.y, e0.z * e1.x - e0.x * e1.z, e0.x * e1.y - e0.y * e1.x };
+                float len2 = n.x * n.x + n.y * n.y + n.z * n.z;
+                float s = len2 > 0.0f ? 1.0f / sqrtf(len2) : 0.0f;
+                if (n.x * d.x + n.y * d.y + n.z * d.z > 0.0f) s = -s;
+                nn[0] = n.x * s; nn[1] = n.y * s; nn[2] = n.z * s; nn[3] = 0.0f;
+            }
+        }
+    }
+    if (hits) *hits = count;
+}
+
 // Single-call helpers so tests can pin the scalar pieces (KATs).
 int orc_ray_box(const float* o3, const float* invdir3, const float* pmin3, const float* pmax3) {
     V3 o = { o3[0], o3[1], o3[2] }, i = { invdir3[0], invdir3[1], invdir3[2] };

@@ -63,6 +63,15 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
     wl.nodes = nodes
     wl.positions = positions
     wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
+    return relight(wl, light, spp)
+
+
+def relight(wl, light="point", spp=1):
+    """The same scene, camera and G-buffer under another light / sample count (a shallow copy of `wl`)."""
+    import copy
+    wl = copy.copy(wl)
+    sc = wl.scene
+    wl.spp = spp
     if light == "directional":
         wl.light = None if spp <= 1 else api.Light.make(api.Light.DIRECTIONAL, sc.light_direction,
                                                         scenes.jitter_offsets(spp, 0.05))
@@ -70,7 +79,7 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
         radius = 0.01 * float(np.linalg.norm(sc.bbox_max - sc.bbox_min))
         wl.light = api.Light.make(api.Light.POINT, sc.light_point,
                                   scenes.jitter_offsets(spp, radius) if spp > 1 else None)
-    wl.rays = W * H * max(1, spp)
+    wl.rays = wl.W * wl.H * max(1, spp)
     return wl
 
 

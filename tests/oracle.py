@@ -37,6 +37,9 @@ _o.orc_ray_tri.argtypes = [C.c_void_p] * 5
 _o.orc_epsilon_for.restype = C.c_float
 _o.orc_epsilon_for.argtypes = [C.c_float, C.c_uint32]
 _o.orc_max_threads.restype = C.c_int
+_o.orc_primary_gbuffer.restype = None
+_o.orc_primary_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
 
 class OLight(C.Structure):
@@ -142,6 +145,20 @@ def brute_force_rays(packed, prim_count, rays):
     out = np.zeros(rays.shape[0], np.uint8)
     _o.orc_brute_force_rays(_p(packed), prim_count, _p(rays), rays.shape[0], _p(out))
     return out
+
+
+def primary_gbuffer(packed, eye, target, fovy, W, H, cull=True, threads=0):
+    """(positions[H,W,4], normals[H,W,4], hits): the G-buffer targets of Model.frag:35-39 by closest hit (see
+    orc_primary_gbuffer); cull=False = brute force over every triangle."""
+    packed = np.ascontiguousarray(packed, np.uint32)
+    eye = np.ascontiguousarray(eye, np.float32)
+    target = np.ascontiguousarray(target, np.float32)
+    pos = np.zeros((H, W, 4), np.float32)
+    nrm = np.zeros((H, W, 4), np.float32)
+    hits = np.zeros(1, np.uint64)
+    _o.orc_primary_gbuffer(_p(packed), _p(eye), _p(target), C.c_float(fovy), W, H, int(bool(cull)), _p(pos), _p(nrm),
+                           _p(hits), threads)
+    return pos, nrm, int(hits[0])
 
 
 def ray_box(o3, invdir3, pmin3, pmax3):

@@ -42,6 +42,24 @@ def test_primary_positions_land_on_the_geometry():
     assert (pos[~hit] == 0).all()                                   # background = clear value
 
 
+@pytest.mark.parametrize("scene,W,H", [("cornell", 160, 120), ("atrium", 320, 180), ("terrain", 200, 150)])
+def test_gbuffer_pass_equals_the_independent_closest_hit_oracle(scene, W, H):
+    """the harness G-buffer (producer of binding 2, contract Model.frag:35-39: camera-relative world
+    position, background = clear value) against oracle/'s own closest-hit (explicit-stack descent, written separately):
+    positions AND normals bit-for-bit.  On the small scene the oracle's traversal is itself checked against brute force
+    over every triangle (no boxes)."""
+    wl = workloads.prepare(scenes.terrain(40) if scene == "terrain" else scene, W, H, via_obj=False)
+    sc = wl.scene
+    pos, nrm, hits = api.primary_gbuffer(wl.packed, sc.eye, sc.target, sc.fovy, W, H)
+    opos, onrm, ohits = oracle.primary_gbuffer(wl.packed, sc.eye, sc.target, sc.fovy, W, H)
+    assert hits == ohits and 0 < hits <= W * H
+    assert (pos.view(np.uint32) == opos.view(np.uint32)).all()
+    assert (nrm.view(np.uint32) == onrm.view(np.uint32)).all()
+    if scene != "atrium":
+        bpos, bnrm, bhits = oracle.primary_gbuffer(wl.packed, sc.eye, sc.target, sc.fovy, W, H, cull=False)
+        assert bhits == ohits and (bpos.view(np.uint32) == opos.view(np.uint32)).all()
+
+
 def test_obj_route_equals_in_memory_route():
     a = workloads.prepare("cornell", 32, 32, via_obj=True)
     b = workloads.prepare("cornell", 32, 32, via_obj=False)
