@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: any-hit shadow rays at 3840x2160 on the ~1M-triangle scene (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config city_4k] [--kernel V] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config city_4k] [--kernel V] [--scaling strong|weak]
 
 A "step" is one pass of the hot path over one frame of synthetic input: one shadow-mask dispatch
 (ray generation + BVH traversal + mask write) with the BVH, the G-buffer positions and the mask
@@ -9,19 +9,38 @@ already resident in HBM.  For N > 1 the driver starts one process per GPU
 (python -m torch.distributed.run ...); ranks exchange nothing on the data path (BVH replicated
 once per GPU, disjoint output), torch.distributed (gloo) is only the barrier / max-over-ranks.
 
-  --scaling weak   (default) every rank traces a full frame of its own (rank r = frame r of a camera
-                   path), so per-GPU work is fixed and value = N * rays / time.
-  --scaling strong ONE frame, row-striped over the ranks in interleaved 32-row bands, one dispatch per GPU (configs[3]).
+  --scaling strong (default) ONE frame, row-striped over the ranks in interleaved 32-row bands, one dispatch per
+                   GPU and step: BASELINE configs[3].  At N = 1 this is the whole frame (configs[2]).
+  --scaling weak   every rank traces a full frame of its own (rank r = frame r of a camera path).
+
+Timing: a time-based pre-warm (back-to-back launches until the clocks have ramped), W untimed warm-up steps, then
+exactly K steps between barrier + synchronize on both sides; `value` = rays / (max over ranks of that wall time).
+Every step is also bracketed by HIP events on the launch stream: `ms_per_frame_gpu_median` is the figure the
+reference's on-screen counter shows (RayTracedShadows.cpp:263-265).
 
 Rank 0 prints ONE JSON line.  Before timing, every rank checks its GPU mask against the CPU oracle
-on every pixel of its frame (the correctness gate of SURVEY.md 8d); a mismatch aborts.
+on every pixel it owns (the correctness gate of SURVEY.md 8d); a mismatch aborts.
+
+`roofline` (N = 1): two bounds the dominant kernel is actually under, each a fraction <= 1 --
+  hbm         bytes that crossed the L2's memory side per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate --pmc
+              passes of THIS command run as child processes before this process touches the GPU; FETCH_SIZE scaled by a
+              factor calibrated in the same pass on a frame whose read volume is known) / launch time / 8 TB/s
+  valu_issue  wave64 VALU instructions per launch (SQ_INSTS_VALU, same mechanism) / (launch time x measured shader
+              clock x 1024 SIMDs) against 0.5 per clock per SIMD (MI355X_MICROARCH.md: 2 cycles per wave64 VALU op)
+`bound` names the larger fraction.  The cache-oblivious figure of SURVEY.md 8d (32 V + 16 L + 17 bytes per ray) is
+kept as `algorithmic_*`: it exceeds the HBM peak several times because the packet kernel fetches a node once per wave
+through the scalar cache, so it prices the shader's memory behaviour, not this kernel's.
 """
 import argparse
-import ctypes
+import csv
 import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,27 +50,158 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the oracle's OpenMP work
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_PEAK_PER_CLK_SIMD = 0.5   # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+SIMDS = 256 * 4
+BAND = 32
+
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"],
+              ["TCC_HIT_sum", "TCC_MISS_sum"]]
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def load_traffic(kernel_name, workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/*traffic*.json), or None."""
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "*traffic*.json"), recursive=True)):
+def source_hash():
+    """Identifies the kernel build a set of counters belongs to."""
+    h = hashlib.sha256()
+    for rel in ("rts_kernels.hip", "rts_packet_asm.inc", "rts_device.h", "Makefile"):
+        h.update(open(os.path.join(ROOT, "raytracedshadows_amd", "csrc", rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# counters: rocprofv3 child passes of this very command (N = 1 only), run BEFORE this process initialises the GPU
+# ---------------------------------------------------------------------------------------------------------------
+def _per_dispatch(csv_dir, kernel_substr="shadowMask"):
+    """{counter: [value per dispatch, in dispatch order]} summed over the rows rocprofv3 writes per dispatch."""
+    acc = {}
+    for path in glob.glob(os.path.join(csv_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if kernel_substr not in r.get("Kernel_Name", ""):
+                    continue
+                key = (r["Counter_Name"], int(r["Dispatch_Id"]))
+                acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
+    out = {}
+    for (name, did) in sorted(acc, key=lambda k: k[1]):
+        out.setdefault(name, []).append(acc[(name, did)])
+    return out
+
+
+def live_counters(args, say):
+    """Runs `bench.py --pmc-child` under rocprofv3 once per counter group; returns a dict or None."""
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        say("rocprofv3 not found: no live counters")
+        return None
+    work = tempfile.mkdtemp(prefix="rts_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--kernel", str(args.kernel)]
+    res = {"source": "live: rocprofv3 --pmc child passes of this command in this run", "passes": []}
+    t_all = time.time()
+    try:
+        # pass 0: kernel trace (durations under the profiler, grid, registers)
+        d = os.path.join(work, "trace")
+        r = subprocess.run([prof, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                           capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            say(f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {r.stderr[-300:]}")
+            return None
+        manifest = json.loads(r.stdout.strip().splitlines()[-1])
+        n_cal, n_real = manifest["calib_launches"], manifest["real_launches"]
+        durs = []
+        for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            with open(path, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if "shadowMask" in row.get("Kernel_Name", ""):
+                        durs.append((int(row["Dispatch_Id"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), row))
+        durs.sort(key=lambda t: t[0])
+        if len(durs) != n_cal + n_real:
+            say(f"kernel trace has {len(durs)} shadow dispatches, expected {n_cal + n_real}: no live counters")
+            return None
+        real = [t[1] for t in durs[n_cal:]]
+        row = durs[-1][2]
+        res["kernel_trace"] = {"kernel": row["Kernel_Name"], "launches": n_real, "avg_ns": sum(real) / len(real),
+                               "median_ns": sorted(real)[len(real) // 2],
+                               "grid": [int(row.get("Grid_Size_X", 0) or 0), int(row.get("Grid_Size_Y", 0) or 0)],
+                               "workgroup": int(row.get("Workgroup_Size_X", 0) or 0),
+                               "vgpr": int(row.get("VGPR_Count", 0) or 0), "sgpr": int(row.get("SGPR_Count", 0) or 0)}
+        counters, calib = {}, {}
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(work, f"pmc{i}")
+            r = subprocess.run([prof, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                               env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                say(f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode}): {r.stderr[-300:]}")
+                continue
+            per = _per_dispatch(d)
+            for name, vals in per.items():
+                if len(vals) != n_cal + n_real:
+                    continue
+                calib[name] = sum(vals[:n_cal]) / n_cal
+                counters[name] = sum(vals[n_cal:]) / n_real
+            res["passes"].append(group)
+        res["counters_per_launch"] = counters
+        res["calibration_counters_per_launch"] = calib
+        res["calibration"] = manifest["calibration"]
+        res["seconds"] = round(time.time() - t_all, 1)
+        return res if counters else None
+    except Exception as e:                                    # a profiler problem must never cost the benchmark line
+        say(f"live counters failed: {e!r}")
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def committed_counters(kname, config, say):
+    """Fallback: the newest profiles/**/counters_*.json whose kernel source hash, kernel and workload match."""
+    want = source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "counters_*.json"), recursive=True), reverse=True):
         try:
             rec = json.load(open(path))
         except Exception:
             continue
-        for r in rec if isinstance(rec, list) else [rec]:
-            if r.get("kernel") == kernel_name and r.get("workload") == workload:
-                best = r
-    return best
+        if rec.get("source_hash") == want and rec.get("workload") == config and rec.get("kernel") == kname:
+            rec["source"] = os.path.relpath(path, ROOT) + " (committed; kernel source hash matches this build)"
+            return rec
+    say("no committed counter summary matches this kernel build: roofline.traffic = null")
+    return None
 
 
+def pmc_child(args):
+    """The command the profiler passes run: a few launches on the calibration frame (1-triangle BVH: the read volume is
+    the position stream, known), then on the real one.  Prints a one-line manifest."""
+    from raytracedshadows_amd import api, workloads
+    wl = workloads.prepare_config(args.config, cache=True)
+    W, H = wl.W, wl.H
+    tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
+    one = api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes
+    n_cal, n_real = 6, 24
+    with api.ShadowContext(0) as ctx:
+        if args.kernel >= 0:
+            ctx.set_option("kernel", args.kernel)
+        d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+        ctx.h2d(d_pos, wl.positions)
+        ctx.set_bvh(one)
+        for _ in range(n_cal):
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        ctx.synchronize()
+        ctx.set_bvh(wl.packed)
+        for _ in range(n_real):
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        ctx.synchronize()
+        kname = ctx.last_kernel_name()
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+    print(json.dumps({"calib_launches": n_cal, "real_launches": n_real, "kernel": kname,
+                      "calibration": {"known_read_bytes": W * H * 16 + 48, "known_write_bytes": W * H,
+                                      "what": "same frame and light, BVH of one far-away triangle: reads = the position stream"}}))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,9 +209,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="city_4k")
     ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = library default)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     # stdout carries exactly ONE JSON line (rank 0): everything else any library prints to fd 1 (gloo announces
     # its connections there) goes to stderr
@@ -74,6 +229,7 @@ def main():
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     N = world
+    say = log if rank == 0 else (lambda *a: None)
 
     dist = None
     if N > 1:
@@ -85,8 +241,8 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
 
     scene_name, W, H, light_kind, spp = workloads.CONFIGS[args.config]
-    say = log if rank == 0 else (lambda *a: None)
     host_threads = max(1, (os.cpu_count() or 1) // max(1, N))
+    striped = args.scaling == "strong" and N > 1
 
     # ---- inputs (untimed): scene -> OBJ -> BVH -> camera -> G-buffer positions -------------------
     # N > 1: the BVH is built ONCE (rank 0) and broadcast as the packed Appendix-A stream (control plane, gloo);
@@ -109,12 +265,18 @@ def main():
             buf.copy_(torch.from_numpy(built.view(np.int32)))
         dist.broadcast(buf, src=0)
         shared_packed = buf.numpy().view(np.uint32)
-    wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say,
-                           via_obj=not dist, packed=shared_packed)
+    if dist:
+        wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say,
+                               via_obj=False, packed=shared_packed)
+    else:
+        wl = workloads.prepare_config(args.config, cache=True, threads=host_threads, log=say)
     rays_per_frame = wl.rays
 
-    BAND = 32
-    striped = args.scaling == "strong" and N > 1
+    # ---- counters of this command, collected by child processes while this one has not touched the GPU yet ----
+    counters = None
+    if N == 1 and not args.no_pmc:
+        counters = live_counters(args, say)
+
     my_rows = partition.stripe_rows(H, N, rank, band=BAND, interleaved=True) if striped else [(0, H)]
     my_rays = sum(e - b for b, e in my_rows) * W * max(1, spp)
 
@@ -129,11 +291,11 @@ def main():
     ctx.h2d(d_pos, wl.positions)
     ctx.h2d(d_mask, np.zeros((H, W), np.uint8))
 
-    def one_step():                       # ONE dispatch per step on every rank
+    def one_step(c=ctx):                  # ONE dispatch per step on every rank
         if striped:
-            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, BAND, N, rank, light=wl.light)
+            c.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, BAND, N, rank, light=wl.light)
         else:
-            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            c.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
 
     # ---- correctness gate: GPU mask == CPU oracle mask, every pixel this rank owns -----------------
     import oracle  # the checker; never on the measured path
@@ -149,44 +311,87 @@ def main():
     ctx.synchronize()
     got = np.zeros((H, W), np.uint8)
     ctx.d2h(got, d_mask)
-    mismatches = int((got != want).sum())
+    own = np.zeros(H, bool)
+    for b, e in my_rows:
+        own[b:e] = True
+    mismatches = int((got[own] != want[own]).sum())
     if mismatches:
         raise SystemExit(f"rank {rank}: GPU mask differs from the CPU oracle on {mismatches} pixels -- not timing")
     say(f"parity gate: {my_rays} rays bit-exact vs oracle (V/ray {V / my_rays:.2f}, L/ray {L / my_rays:.2f})")
     alg_bytes_per_step = 32 * V + 16 * L + 17 * (my_rays // max(1, spp))
+    kname = ctx.last_kernel_name()
+
+    # ---- pre-warm: back-to-back launches until the clocks have ramped (the parity gate left the GPU idle for seconds;
+    #      five warm-up frames are 1 ms of work) -------------------------------------------------------------------
+    t0 = time.perf_counter()
+    prewarm_launches = 0
+    while time.perf_counter() - t0 < args.prewarm_seconds:
+        for _ in range(50):
+            one_step()
+        ctx.synchronize()
+        prewarm_launches += 50
 
     # ---- timed region -------------------------------------------------------------------------------
     for _ in range(args.warmup):
         one_step()
-    ctx.synchronize()
     if dist:
         dist.barrier()
+    ctx.synchronize()
     t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ctx.timer_mark(i)
         one_step()
-    ctx.timer_end()
+    ctx.timer_mark(args.steps)
     ctx.synchronize()
+    wall = time.perf_counter() - t0
     if dist:
         dist.barrier()
-    wall = time.perf_counter() - t0
-    kernel_ms = ctx.timer_elapsed_ms()          # HIP events on the launch stream, whole timed region
+    per_launch = np.array([ctx.timer_between_ms(i, i + 1) for i in range(args.steps)])   # HIP events, launch stream
+    kernel_ms = float(per_launch.sum())
+    median_ms = float(np.median(per_launch))
+
+    # ---- the same dispatch against a one-triangle BVH: what the frame costs before any traversal ----------------
+    tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
+    floor_ctx = api.ShadowContext(device)
+    floor_ctx.set_bvh(api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes)
+    if args.kernel >= 0:
+        floor_ctx.set_option("kernel", args.kernel)
+    for _ in range(20):
+        one_step(floor_ctx)
+    fl = []
+    for i in range(30):
+        floor_ctx.timer_mark(0)
+        one_step(floor_ctx)
+        floor_ctx.timer_mark(1)
+        fl.append(floor_ctx.timer_between_ms(0, 1))
+    floor_ms = float(np.median(fl))
+    floor_ctx.close()
+    ctx.h2d(d_mask, got)                                            # (the floor frames overwrote the mask)
+
+    # ---- shader clock held under this load (diagnostics build of the same kernel, after the timed region) --------
+    clock_mhz = None
+    if kname.startswith("shadowMaskPacketKernel") and not striped:
+        try:
+            for _ in range(50):
+                one_step()
+            clock_mhz = ctx.measure_shader_clock_mhz(one_step, ((W + 7) // 8) * ((H + 7) // 8))
+        except Exception as e:
+            say(f"clock measurement failed: {e!r}")
+
     if dist:
         import torch
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms_max = float(t[0]), float(t[1])
+        t = torch.tensor([wall, kernel_ms, median_ms, floor_ms], dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(N)]
+        dist.all_gather(gathered, t)
+        per_rank = [[float(x) for x in g] for g in gathered]
+        wall = max(g[0] for g in per_rank)                          # MAX over ranks
     else:
-        kernel_ms_max = kernel_ms
+        per_rank = [[wall, kernel_ms, median_ms, floor_ms]]
 
-    total_rays = rays_per_frame * (N if args.scaling == "weak" else 1) * args.steps
+    frames_per_step = N if (args.scaling == "weak" and N > 1) else 1
+    total_rays = rays_per_frame * frames_per_step * args.steps
     value = total_rays / wall / 1e6
-    launches = args.steps
-    avg_launch_s = kernel_ms / 1e3 / launches
-    achieved = alg_bytes_per_step / avg_launch_s / 1e9  # GB/s of algorithmic bytes
-    kname = ctx.last_kernel_name()
-    # the committed PMC pass measured a whole frame on one GPU; a stripe of a frame is a different launch
-    traffic = load_traffic(kname, args.config) if not (args.scaling == "strong" and N > 1) else None
+    avg_launch_s = kernel_ms / 1e3 / args.steps
 
     result = {
         "metric": "shadow Mrays/s", "value": round(value, 1), "unit": "Mrays/s",
@@ -195,30 +400,70 @@ def main():
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {scene_name} ({wl.prim_count} triangles, procedural stand-in), "
                                f"{W}x{H}, 1 {light_kind} light, {max(1, spp)} spp, "
-                               f"{'one frame per GPU' if args.scaling == 'weak' else 'one frame row-striped over GPUs'}",
+                               + ("one frame per GPU" if frames_per_step > 1 else
+                                  f"one frame row-striped over {N} GPUs in interleaved {BAND}-row bands" if striped else "one frame"),
                    "rays_per_frame": rays_per_frame, "kernel": kname, "bvh_bytes": int(wl.packed.nbytes),
-                   "ms_per_frame_gpu_events": round(kernel_ms_max / args.steps, 4)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                     "algorithmic_bytes_per_launch": int(alg_bytes_per_step),
-                     "avg_launch_ms": round(avg_launch_s * 1e3, 5), "kernel": kname,
-                     "note": "algorithmic (cache-oblivious) bytes 32*V+16*L+17/px from the oracle's exact visit counts; "
-                             "frac > 1 means the node stream is served from L2/Infinity Cache, not HBM"},
+                   "ms_per_frame_gpu_median": round(max(g[2] for g in per_rank), 4),
+                   "ms_per_frame_gpu_mean": round(max(g[1] for g in per_rank) / args.steps, 4),
+                   "dispatch_floor_ms": round(max(g[3] for g in per_rank), 4),
+                   "prewarm_launches": prewarm_launches},
     }
+    if N > 1:
+        result["config"]["per_rank"] = [{"rank": r, "wall_ms_per_step": round(g[0] / args.steps * 1e3, 4),
+                                         "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": round(g[3], 4)}
+                                        for r, g in enumerate(per_rank)]
 
-    # informative extra: instruction-issue view of the same launch.  VALU wave-instructions per launch
-    # come from the committed rocprofv3 PMC pass of this kernel + workload, the ceiling from the microbenchmark
-    # (profiles/r01/microbench_valu_issue.log); the duration is this run's.
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "packet_final_city4k_summary.json")))
-        if args.config == "city_4k" and kname == "shadowMaskPacketKernel<1>" and not striped:
-            valu = prof["counters_avg_per_dispatch"]["SQ_INSTS_VALU"]
-            per_clk = valu / (avg_launch_s * 2.4e9 * 1024)
-            result["valu_issue"] = {"achieved": round(per_clk, 3), "peak": 0.325, "unit": "wave64 VALU instr / clk / SIMD (2.4 GHz)",
-                                    "frac": round(per_clk / 0.325, 3), "valu_instr_per_launch": int(valu)}
-    except Exception:
-        pass
+    # ---- roofline (N = 1) -------------------------------------------------------------------------------------------
+    roof = {"algorithmic_bytes_per_launch": int(alg_bytes_per_step),
+            "algorithmic_GBps": round(alg_bytes_per_step / avg_launch_s / 1e9, 1),
+            "avg_launch_ms": round(avg_launch_s * 1e3, 5), "median_launch_ms": round(median_ms, 5), "kernel": kname,
+            "shader_clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+            "note": "frac = the larger of two measured bounds (see the module docstring); algorithmic_* is SURVEY 8d's "
+                    "cache-oblivious 32V+16L+17 B/ray from the oracle's exact visit counts, informational"}
+    if N == 1 and counters is None and not args.no_pmc:
+        counters = committed_counters(kname, args.config, say)
+    hbm = issue = None
+    if counters:
+        c, cal = counters["counters_per_launch"], counters.get("calibration_counters_per_launch", {})
+        known = counters.get("calibration", {})
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            # gfx950: FETCH_SIZE reads 1/2 of a wide (16 B/lane) stream (MI355X_MICROARCH.md, HBM); calibrated in the same
+            # pass against the frame whose read volume is known rather than assumed
+            factor = known["known_read_bytes"] / (cal["FETCH_SIZE"] * 1024) if cal.get("FETCH_SIZE") else 2.0
+            fetch = c["FETCH_SIZE"] * 1024 * factor
+            write = c["WRITE_SIZE"] * 1024                       # exact for streaming stores; byte stores count 32-B sectors
+            traffic = fetch + write
+            hbm = {"bytes_per_launch": int(traffic), "fetch_bytes": int(fetch), "write_bytes": int(write),
+                   "fetch_factor_calibrated": round(factor, 4),
+                   "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+            if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+                hbm["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        if "SQ_INSTS_VALU" in c and clock_mhz:
+            per = c["SQ_INSTS_VALU"] / (avg_launch_s * clock_mhz * 1e6 * SIMDS)
+            issue = {"valu_instr_per_launch": int(c["SQ_INSTS_VALU"]), "achieved": round(per, 4),
+                     "peak": VALU_PEAK_PER_CLK_SIMD, "unit": "wave64 VALU instr / clk / SIMD",
+                     "frac": round(per / VALU_PEAK_PER_CLK_SIMD, 4)}
+            for k in ("SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES"):
+                if k in c:
+                    issue[k.lower()] = int(c[k])
+            if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+                issue["wait_any_share_of_wave_cycles"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+        roof["counters_source"] = counters.get("source")
+        roof["source_hash"] = source_hash()
+        if "kernel_trace" in counters:
+            roof["profiler_avg_launch_ms"] = round(counters["kernel_trace"]["avg_ns"] / 1e6, 5)
+            roof["kernel_trace"] = counters["kernel_trace"]
+    pick = max([b for b in (("hbm", hbm), ("valu_issue", issue)) if b[1]], key=lambda b: b[1]["frac"], default=None)
+    if pick:
+        roof.update({"bound": pick[0], "achieved": pick[1]["achieved"], "peak": pick[1]["peak"], "unit": pick[1]["unit"],
+                     "frac": pick[1]["frac"]})
+    else:
+        roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+    roof["traffic"] = hbm["bytes_per_launch"] if hbm else None
+    roof["hbm"] = hbm
+    roof["valu_issue"] = issue
+    result["roofline"] = roof
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on the host cores, same frame ---------------
     if rank == 0 and N == 1 and not args.no_cpu_baseline:

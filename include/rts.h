@@ -179,6 +179,12 @@ int rts_stream_synchronize(rts_ctx* ctx, void* stream);
 int rts_timer_begin(rts_ctx* ctx, void* stream);
 int rts_timer_end(rts_ctx* ctx, void* stream);
 int rts_timer_elapsed_ms(rts_ctx* ctx, float* ms);
+/* Per-launch timing: hipEvents in numbered slots (0..65535, created on first use).  rts_timer_mark records slot `slot`
+ * on `stream`; rts_timer_between_ms synchronises on slot_b and returns the time from slot_a to slot_b.  A mark before
+ * every dispatch of a frame loop gives the per-frame GPU times whose median the reference shows
+ * (120-frame average of Timestamp_Shadows, cpp:263-265). */
+int rts_timer_mark(rts_ctx* ctx, void* stream, uint32_t slot);
+int rts_timer_between_ms(rts_ctx* ctx, uint32_t slot_a, uint32_t slot_b, float* ms);
 /* Name of the kernel the last trace launched (for matching rocprofv3 rows). */
 const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
 /* Dispatch order of the image tiles for traces whose workgroup count equals `count`: workgroup i works on tile
@@ -192,6 +198,9 @@ int rts_device_mem_info(rts_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
  * those iterations (0-31)};
  * this copies them out. */
 int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
+/* Same launch, 2 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end.  With the
+ * start/end shader clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */
+int rts_ctx_read_wave_realtime(rts_ctx* ctx, uint64_t* out, size_t waves);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,9 @@ _sig("rts_timer_elapsed_ms", C.c_int, C.c_void_p, C.POINTER(C.c_float))
 _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
 _sig("rts_ctx_set_tile_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_ctx_read_wave_realtime", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_timer_mark", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
+_sig("rts_timer_between_ms", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 _sig("rts_device_mem_info", C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _sig("rtsh_primary_positions", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32,
      C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
@@ -341,6 +344,14 @@ class ShadowContext:
         _check(_lib.rts_timer_elapsed_ms(self._h, C.byref(ms)), "rts_timer_elapsed_ms")
         return float(ms.value)
 
+    def timer_mark(self, slot, stream=None):
+        _check(_lib.rts_timer_mark(self._h, C.c_void_p(stream or 0), slot), "rts_timer_mark")
+
+    def timer_between_ms(self, slot_a, slot_b):
+        ms = C.c_float(0)
+        _check(_lib.rts_timer_between_ms(self._h, slot_a, slot_b, C.byref(ms)), "rts_timer_between_ms")
+        return float(ms.value)
+
     def last_kernel_name(self):
         return _lib.rts_ctx_last_kernel_name(self._h).decode()
 
@@ -355,6 +366,31 @@ class ShadowContext:
         out = np.zeros((waves, 4), dtype=np.uint64)
         _check(_lib.rts_ctx_read_wave_stats(self._h, _ptr(out), waves), "rts_ctx_read_wave_stats")
         return out
+
+    def read_wave_realtime(self, waves):
+        out = np.zeros((waves, 2), dtype=np.uint64)
+        _check(_lib.rts_ctx_read_wave_realtime(self._h, _ptr(out), waves), "rts_ctx_read_wave_realtime")
+        return out
+
+    def measure_shader_clock_mhz(self, trace, waves, launches=8):
+        """Clock the chip holds while `trace()` (one dispatch of a packet kernel with `waves` one-wave workgroups) runs
+        back to back: shader clocks per 100 MHz realtime tick, summed over every wave of the last launch
+        (MI355X_MICROARCH.md, DVFS give-back item 6).  Diagnostics build of the kernel; results are not touched."""
+        self.set_option("wave_stats", waves)
+        try:
+            for _ in range(launches):
+                trace()
+            self.synchronize()
+            st = self.read_wave_stats(waves)
+            rt = self.read_wave_realtime(waves)
+        finally:
+            self.set_option("wave_stats", 0)
+        ok = (rt[:, 1] > rt[:, 0]) & (st[:, 1] > st[:, 0])
+        if not ok.any():
+            return None
+        clocks = (st[ok, 1] - st[ok, 0]).astype(np.float64).sum()
+        ticks = (rt[ok, 1] - rt[ok, 0]).astype(np.float64).sum()
+        return float(clocks / ticks * 100.0)
 
 
 # -- harness entry points -----------------------------------------------------------------------

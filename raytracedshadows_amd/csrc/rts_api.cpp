@@ -22,6 +22,7 @@ struct rts_ctx {
     int variant = rts::V_AUTO;
     int swizzle = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> marks;   // rts_timer_mark slots, created on first use
     // staging for the host-pointer entries
     void* d_in = nullptr; size_t inBytes = 0;
     void* d_out = nullptr; size_t outBytes = 0;
@@ -152,6 +153,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
     delete c;
     return RTS_OK;
 }
@@ -197,9 +199,9 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
         if (value > 0) {
-            c->waveStatsBytes = (size_t)value * 32;
-            RTS_HIP(hipMalloc((void**)&c->d_waveStats, c->waveStatsBytes));
-            RTS_HIP(hipMemset(c->d_waveStats, 0, c->waveStatsBytes));
+            c->waveStatsBytes = (size_t)value * 32;           // 4 u64 per wave, then 2 u64 per wave (realtime stamps)
+            RTS_HIP(hipMalloc((void**)&c->d_waveStats, c->waveStatsBytes + (size_t)value * 16));
+            RTS_HIP(hipMemset(c->d_waveStats, 0, c->waveStatsBytes + (size_t)value * 16));
         }
         return RTS_OK;
     }
@@ -254,7 +256,10 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.nBlocks = p.blocksX * p.blocksY;
     p.swizzle = c->swizzle ? 1u : 0u;
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
-    if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) p.waveStats = c->d_waveStats;
+    if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) {
+        p.waveStats = c->d_waveStats;
+        p.waveRealtime = c->d_waveStats + c->waveStatsBytes / 8;
+    }
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
@@ -402,6 +407,25 @@ int rts_timer_elapsed_ms(rts_ctx* c, float* ms) {
     RTS_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return RTS_OK;
 }
+int rts_timer_mark(rts_ctx* c, void* stream, uint32_t slot) {
+    if (!c || slot >= 65536u) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    try {
+        if (c->marks.size() <= slot) c->marks.resize((size_t)slot + 1, nullptr);
+    } catch (...) {
+        return RTS_ERR_CAPACITY;
+    }
+    if (!c->marks[slot]) RTS_HIP(hipEventCreate(&c->marks[slot]));
+    RTS_HIP(hipEventRecord(c->marks[slot], (hipStream_t)stream));
+    return RTS_OK;
+}
+int rts_timer_between_ms(rts_ctx* c, uint32_t a, uint32_t b, float* ms) {
+    if (!c || !ms || a >= c->marks.size() || b >= c->marks.size() || !c->marks[a] || !c->marks[b]) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipEventSynchronize(c->marks[b]));
+    RTS_HIP(hipEventElapsedTime(ms, c->marks[a], c->marks[b]));
+    return RTS_OK;
+}
 const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel : ""; }
 
 int rts_ctx_device_ordinal(rts_ctx* c) { return c ? c->device : 0; }
@@ -447,6 +471,13 @@ int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {
     if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
     RTS_HIP(hipMemcpy(out, c->d_waveStats, waves * 32, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+int rts_ctx_read_wave_realtime(rts_ctx* c, uint64_t* out, size_t waves) {
+    if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMemcpy(out, c->d_waveStats + c->waveStatsBytes / 8, waves * 16, hipMemcpyDeviceToHost));
     return RTS_OK;
 }
 

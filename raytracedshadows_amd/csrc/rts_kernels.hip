@@ -654,6 +654,7 @@ void shadowMaskPacketKernel(TraceParams p) {
     const NodeStream bvh = openStream(p);
     const uint32_t ns = SOFT ? p.nsamples : 1u;
     const uint64_t tStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
+    const uint64_t rStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memrealtime() : 0;
     int32_t left = 0;
     ShareDiag shareDiag;
     shareDiag.on = !PLAIN && p.waveStats != nullptr;
@@ -675,9 +676,13 @@ void shadowMaskPacketKernel(TraceParams p) {
     for (int k = 0; k < K; ++k)
         if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);       // comp:150
     if (!PLAIN && p.waveStats && lane == 0) {    // diagnostics: never read by any kernel, never part of an output
-        uint64_t* o = p.waveStats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave) * 4;
+        const size_t slot = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave;
+        uint64_t* o = p.waveStats + slot * 4;
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
+        // shader clocks against the 100 MHz reference over the same interval: the clock the chip held under this load
+        p.waveRealtime[slot * 2] = rStart;
+        p.waveRealtime[slot * 2 + 1] = __builtin_amdgcn_s_memrealtime();
         // dissolved flag | lane-per-ray iterations after the dissolve | clocks from start to the dissolve
         o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
                ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);

@@ -67,8 +67,16 @@ def test_generic(k):
     return L
 
 
+# Every loop starts with the same two instructions: a packet that has no node left (cur == END) must never reach the
+# node load -- END * 32 wraps to byte offset 0xFFFFFFE0, 4 GiB - 32 B past the stream (the one scalar-load fault on
+# record).  All callers already guarantee cur != END; the guard makes it a property of the loop itself.
+ENTRY_GUARD = ["s_cmp_eq_u32 %[cur], -1",
+               "s_cbranch_scc1 6f"]
+
+
 def loop(K, form):
-    L = ["s_lshl_b32 s52, %[cur], 5",
+    L = ENTRY_GUARD + [
+         "s_lshl_b32 s52, %[cur], 5",
          "s_branch 2f",
          "5:",
          "s_add_u32 s52, s52, 32",                      # down-step: the left child is the next node in memory
@@ -139,7 +147,8 @@ def loop_prefetch(form):
     k = 0
     test = test_generic(k) if form == 8 else test_ordered(k, form)
     r = "s[54:55]"
-    L = ["s_lshl_b32 s52, %[cur], 5",
+    L = ENTRY_GUARD + [
+         "s_lshl_b32 s52, %[cur], 5",
          "2:",                                           # (re)load: current node + its sequential successor
          "s_load_dwordx8 s[40:47], %[base], s52",
          "s_add_u32 s53, s52, 32",
@@ -214,7 +223,8 @@ def loop_leaf(form):
     link: the caller finds the lowest waiting node)."""
     test = test_generic(0) if form == 8 else test_ordered(0, form)
     r = "s[54:55]"
-    L = ["s_lshl_b32 s52, %[cur], 5",
+    L = ENTRY_GUARD + [
+         "s_lshl_b32 s52, %[cur], 5",
          "s_branch 2f",
          "5:",
          "s_add_u32 s52, s52, 32",
