@@ -198,8 +198,9 @@ int rts_device_mem_info(rts_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
  * those iterations (0-31)};
  * this copies them out. */
 int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
-/* Same launch, 2 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end.  With the
- * start/end shader clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */
+/* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks
+ * from the wave's start to its first ray being ready (G-buffer texel in, ray set up), XCC id.  With the start/end shader
+ * clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */
 int rts_ctx_read_wave_realtime(rts_ctx* ctx, uint64_t* out, size_t waves);
 
 #ifdef __cplusplus

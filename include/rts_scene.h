@@ -45,6 +45,13 @@ int rtsh_primary_gbuffer_device(rts_ctx* ctx, const float eye[3], const float ta
 int rtsh_combine(const rts_constants* constants, const rts_light* light, const float* positions, const float* normals,
                  const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb);
 
+/* The combine pass on the GPU (same per-pixel arithmetic, shared source): DEVICE buffers, d_rgb = W*H*3 bytes,
+ * asynchronous on `stream`.  Together with rtsh_primary_gbuffer_device and rts_trace_shadow_mask_device the whole
+ * frame -- G-buffer, shadow mask, lighting -- stays on the device (tools/render.py). */
+int rtsh_combine_device(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                        const float* d_normals, const uint8_t* d_mask, uint32_t W, uint32_t H, uint8_t* d_rgb,
+                        void* stream);
+
 /* OBJ ingest.  rtsh_obj_load parses `path` and expands it to the reference's flat
  * Vertex stream: 8 floats per vertex (position.xyz, normal.xyz, texcoord.uv), indices[i] = i.
  * Call with vertices == NULL to query *vertex_count (3 per triangle) first.  Returns RTS_OK,

@@ -149,6 +149,8 @@ _sig("rtsh_primary_gbuffer", C.c_int, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_
      C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int)
 _sig("rtsh_primary_gbuffer_device", C.c_int, C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p,
      C.c_void_p, C.c_void_p)
+_sig("rtsh_combine_device", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
 _sig("rtsh_combine", C.c_int, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_uint32, C.c_uint32, C.c_void_p)
 _sig("rtsh_obj_load", C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, _u32p, _f32p, _f32p)
@@ -368,7 +370,7 @@ class ShadowContext:
         return out
 
     def read_wave_realtime(self, waves):
-        out = np.zeros((waves, 2), dtype=np.uint64)
+        out = np.zeros((waves, 4), dtype=np.uint64)
         _check(_lib.rts_ctx_read_wave_realtime(self._h, _ptr(out), waves), "rts_ctx_read_wave_realtime")
         return out
 
@@ -439,6 +441,14 @@ def combine(constants, light, positions, normals, mask):
     _check(_lib.rtsh_combine(C.byref(constants), lp, _ptr(positions) if positions is not None else None, _ptr(normals),
                              _ptr(mask), W, H, _ptr(rgb)), "rtsh_combine")
     return rgb
+
+
+def combine_device(ctx, constants, light, d_positions, d_normals, d_mask, width, height, d_rgb, stream=None):
+    """Combine.frag on the GPU: device pointers, d_rgb = width*height*3 bytes, asynchronous."""
+    lp = C.byref(light) if light is not None else None
+    _check(_lib.rtsh_combine_device(ctx.handle, C.byref(constants), lp, C.c_void_p(d_positions or 0), C.c_void_p(d_normals),
+                                    C.c_void_p(d_mask), width, height, C.c_void_p(d_rgb), C.c_void_p(stream or 0)),
+           "rtsh_combine_device")
 
 
 def write_ppm(path, rgb):

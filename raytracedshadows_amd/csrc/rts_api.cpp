@@ -199,9 +199,9 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
         if (value > 0) {
-            c->waveStatsBytes = (size_t)value * 32;           // 4 u64 per wave, then 2 u64 per wave (realtime stamps)
-            RTS_HIP(hipMalloc((void**)&c->d_waveStats, c->waveStatsBytes + (size_t)value * 16));
-            RTS_HIP(hipMemset(c->d_waveStats, 0, c->waveStatsBytes + (size_t)value * 16));
+            c->waveStatsBytes = (size_t)value * 32;           // 4 u64 per wave, then 4 more per wave (realtime stamps)
+            RTS_HIP(hipMalloc((void**)&c->d_waveStats, c->waveStatsBytes * 2));
+            RTS_HIP(hipMemset(c->d_waveStats, 0, c->waveStatsBytes * 2));
         }
         return RTS_OK;
     }
@@ -477,7 +477,7 @@ int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {
 int rts_ctx_read_wave_realtime(rts_ctx* c, uint64_t* out, size_t waves) {
     if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
-    RTS_HIP(hipMemcpy(out, c->d_waveStats + c->waveStatsBytes / 8, waves * 16, hipMemcpyDeviceToHost));
+    RTS_HIP(hipMemcpy(out, c->d_waveStats + c->waveStatsBytes / 8, waves * 32, hipMemcpyDeviceToHost));
     return RTS_OK;
 }
 

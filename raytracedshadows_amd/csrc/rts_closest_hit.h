@@ -96,4 +96,28 @@ RTS_HD void shadePixel(const uint32_t* bvh, const Camera& c, uint32_t x, uint32_
     }
 }
 
+// Combine.frag:18-37 with baseColor = 1 (the default white material, RayTracedShadows.cpp:1013-1018), one pixel:
+//   direct  = 1.25 * max(0, N.L) * shadowMask            shadowMask = mask / samples
+//   ambient = 0.15 + 0.05 * (1 - max(0, N.(-cameraDirection)))
+//   pixel discarded (left 0) where the normal is 0 (background)
+// L = the light direction for a directional light; for the point-light extension L = normalize(light - P).
+struct CombineParams { V3 cam, viewDir /* normalised */, light; uint32_t pointLight; float samples; };
+
+RTS_HD uint8_t combinePixel(const CombineParams& c, const float* position4, const float* normal4, uint8_t mask) {
+    V3 n{ normal4[0], normal4[1], normal4[2] };
+    if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) return 0;
+    V3 L = c.light;
+    if (c.pointLight) {
+        V3 p{ c.cam.x + position4[0], c.cam.y + position4[1], c.cam.z + position4[2] };
+        L = sub(L, p);
+        float ll = __builtin_sqrtf(dot(L, L));
+        if (ll > 0) L = mul(L, 1.0f / ll);
+    }
+    float ndl = dot(n, L); if (ndl < 0) ndl = 0;
+    float ndv = dot(n, mul(c.viewDir, -1.0f)); if (ndv < 0) ndv = 0;
+    float v = 1.25f * ndl * ((float)mask / c.samples) + 0.15f + 0.05f * (1.0f - ndv);
+    int q = (int)(v * 255.0f + 0.5f); if (q > 255) q = 255; if (q < 0) q = 0;
+    return (uint8_t)q;
+}
+
 } // namespace rts_harness

@@ -40,7 +40,7 @@ struct TraceParams {
     uint64_t nrays;
     const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
-    uint64_t* waveRealtime;   // diagnostics: {s_memrealtime at start, at end} per wave (100 MHz), NULL iff waveStats is
+    uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
     float offsets[64][4];

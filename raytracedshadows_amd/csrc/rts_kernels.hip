@@ -661,11 +661,16 @@ void shadowMaskPacketKernel(TraceParams p) {
     uint32_t lit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lit[k] = 0;
+    uint64_t tReady = 0;
     for (uint32_t s = 0; s < ns; ++s) {
         Ray r[K];
         bool occluded[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
+        if (!PLAIN && p.waveStats && s == 0) {       // diagnostics: the G-buffer texel is in and the first ray exists
+            asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
+            tReady = __builtin_amdgcn_s_memtime();
+        }
         traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
@@ -681,8 +686,12 @@ void shadowMaskPacketKernel(TraceParams p) {
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
         // shader clocks against the 100 MHz reference over the same interval: the clock the chip held under this load
-        p.waveRealtime[slot * 2] = rStart;
-        p.waveRealtime[slot * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.waveRealtime[slot * 4] = rStart;
+        p.waveRealtime[slot * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.waveRealtime[slot * 4 + 2] = tReady - tStart;      // clocks from wave start to "first ray ready"
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.waveRealtime[slot * 4 + 3] = xcc;
         // dissolved flag | lane-per-ray iterations after the dissolve | clocks from start to the dissolve
         o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
                ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);

@@ -74,39 +74,37 @@ extern "C" int rtsh_primary_positions(const rts_vec4u* packed, size_t count, con
     return rtsh_primary_gbuffer(packed, count, eye, target, fovy, W, H, positions, nullptr, hit_count, threads);
 }
 
-// Combine.frag:18-37 with baseColor = 1 (the default white material, RayTracedShadows.cpp:1013-1018):
-//   direct  = 1.25 * max(0, N.L) * shadowMask            shadowMask = mask / samples
-//   ambient = 0.15 + 0.05 * (1 - max(0, N.(-cameraDirection)))
-//   pixel discarded (left 0) where the normal is 0 (background)
-// L = constants.lightDirection for a directional light; for the point-light extension L = normalize(light - P).
-extern "C" int rtsh_combine(const rts_constants* k, const rts_light* light, const float* positions, const float* normals,
-                            const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb) {
-    if (!k || !normals || !mask || !rgb || W == 0 || H == 0) return RTS_ERR_INVALID_ARG;
-    if (light && light->type == RTS_LIGHT_POINT && !positions) return RTS_ERR_INVALID_ARG;
-    const float ns = (light && light->nsamples > 1) ? (float)light->nsamples : 1.0f;
+namespace rts_harness {
+// Shared by the host and device combine passes: validates and condenses the arguments.
+int makeCombineParams(const rts_constants* k, const rts_light* light, bool havePositions, CombineParams* out) {
+    if (!k || !out) return RTS_ERR_INVALID_ARG;
+    if (light && light->type == RTS_LIGHT_POINT && !havePositions) return RTS_ERR_INVALID_ARG;
+    CombineParams c;
+    c.samples = (light && light->nsamples > 1) ? (float)light->nsamples : 1.0f;
+    c.cam = V3{ k->cameraPosition[0], k->cameraPosition[1], k->cameraPosition[2] };
     V3 cd{ k->cameraDirection[0], k->cameraDirection[1], k->cameraDirection[2] };
     float cl = std::sqrt(dot(cd, cd));
     if (cl > 0) cd = mul(cd, 1.0f / cl);
+    c.viewDir = cd;
+    c.light = light ? V3{ light->xyz[0], light->xyz[1], light->xyz[2] }
+                    : V3{ k->lightDirection[0], k->lightDirection[1], k->lightDirection[2] };
+    c.pointLight = (light && light->type == RTS_LIGHT_POINT) ? 1u : 0u;
+    *out = c;
+    return RTS_OK;
+}
+} // namespace rts_harness
+
+// Combine pass on the host (Combine.frag:18-37; per-pixel arithmetic in rts_closest_hit.h: combinePixel).
+extern "C" int rtsh_combine(const rts_constants* k, const rts_light* light, const float* positions, const float* normals,
+                            const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb) {
+    if (!k || !normals || !mask || !rgb || W == 0 || H == 0) return RTS_ERR_INVALID_ARG;
+    CombineParams c;
+    int s = makeCombineParams(k, light, positions != nullptr, &c);
+    if (s != RTS_OK) return s;
+    const float zero[4] = { 0, 0, 0, 0 };
     for (size_t i = 0; i < (size_t)W * H; ++i) {
-        V3 n{ normals[i * 4], normals[i * 4 + 1], normals[i * 4 + 2] };
-        uint8_t* o = rgb + i * 3;
-        if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) { o[0] = o[1] = o[2] = 0; continue; }
-        V3 L{ k->lightDirection[0], k->lightDirection[1], k->lightDirection[2] };
-        if (light) {
-            L = V3{ light->xyz[0], light->xyz[1], light->xyz[2] };
-            if (light->type == RTS_LIGHT_POINT) {
-                V3 p{ k->cameraPosition[0] + positions[i * 4], k->cameraPosition[1] + positions[i * 4 + 1],
-                      k->cameraPosition[2] + positions[i * 4 + 2] };
-                L = sub(L, p);
-                float ll = std::sqrt(dot(L, L));
-                if (ll > 0) L = mul(L, 1.0f / ll);
-            }
-        }
-        float ndl = dot(n, L); if (ndl < 0) ndl = 0;
-        float ndv = dot(n, mul(cd, -1.0f)); if (ndv < 0) ndv = 0;
-        float v = 1.25f * ndl * ((float)mask[i] / ns) + 0.15f + 0.05f * (1.0f - ndv);
-        int q = (int)(v * 255.0f + 0.5f); if (q > 255) q = 255; if (q < 0) q = 0;
-        o[0] = o[1] = o[2] = (uint8_t)q;
+        const uint8_t q = combinePixel(c, positions ? positions + i * 4 : zero, normals + i * 4, mask[i]);
+        rgb[i * 3] = rgb[i * 3 + 1] = rgb[i * 3 + 2] = q;
     }
     return RTS_OK;
 }

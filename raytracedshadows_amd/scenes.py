@@ -12,6 +12,8 @@ cornell    Cornell-box-scale OBJ                   1 024       configs[0]  256 x
 atrium     Sponza-class OBJ                        ~250 k      configs[1]  1920 x 1080
 city       ~1M-tri OBJ, below the builder switch   999 488     configs[2-4]  3840 x 2160
 city_big   same, above 1 000 000 primitives        1 034 288   builder's median-split branch
+courtyard  San-Miguel-class OBJ (arcades, trees     999 990     configs[2-4] on the hard case: 60 nodes/ray,
+           of leaf cards, furniture)                            tiles whose rays scatter between leaves
 =========  =====================================  ==========  =========================
 
 Camera and light follow the reference's defaults where it has any (eye = bbox.max + 2 looking at the
@@ -185,6 +187,147 @@ def city_big(seed=3):
     return _city("city_big", seed, 10625)
 
 
+def _tube(p0, p1, r0, r1, sides, segments):
+    """Tapered tube from p0 to p1 (any direction): sides x segments quads."""
+    p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
+    axis = p1 - p0
+    length = np.linalg.norm(axis)
+    w = axis / length
+    a = np.array([1.0, 0, 0]) if abs(w[0]) < 0.9 else np.array([0, 1.0, 0])
+    u = np.cross(w, a)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    ang = np.linspace(0.0, 2.0 * np.pi, sides, endpoint=False)
+    t = np.linspace(0.0, 1.0, segments + 1)
+    rad = r0 + (r1 - r0) * t
+    ring = np.cos(ang)[None, :, None] * u[None, None, :] + np.sin(ang)[None, :, None] * v[None, None, :]
+    verts = (p0[None, None, :] + t[:, None, None] * axis[None, None, :] + rad[:, None, None] * ring).reshape(-1, 3)
+    i = (np.arange(sides)[None, :] + sides * np.arange(segments)[:, None]).reshape(-1)
+    j = (((np.arange(sides) + 1) % sides)[None, :] + sides * np.arange(segments)[:, None]).reshape(-1)
+    faces = np.stack([np.stack([i, j, j + sides], 1), np.stack([i, j + sides, i + sides], 1)], 1).reshape(-1, 3)
+    return verts, faces
+
+
+def _arch(c0, c1, y, rise, depth, thickness, segments):
+    """Semicircular arch band between two column tops c0, c1 (x,z), springing at height y: an extruded strip."""
+    c0, c1 = np.asarray(c0, float), np.asarray(c1, float)
+    mid, half = (c0 + c1) / 2.0, (c1 - c0) / 2.0
+    span = np.linalg.norm(half)
+    dirx = half / span
+    nrm = np.array([-dirx[1], dirx[0]])
+    ang = np.linspace(np.pi, 0.0, segments + 1)
+    parts = []
+    for r in (span, span - thickness):                             # outer and inner face of the band
+        px = mid[None, :] + np.cos(ang)[:, None] * r * dirx[None, :]
+        py = y + np.sin(ang) * r * (rise / span)
+        for s in (-0.5, 0.5):
+            pass
+        a = np.stack([px[:, 0] - nrm[0] * depth / 2, py, px[:, 1] - nrm[1] * depth / 2], 1)
+        b = np.stack([px[:, 0] + nrm[0] * depth / 2, py, px[:, 1] + nrm[1] * depth / 2], 1)
+        verts = np.concatenate([a, b], 0)
+        i = np.arange(segments)
+        n = segments + 1
+        faces = np.concatenate([np.stack([i, i + 1, i + 1 + n], 1), np.stack([i, i + 1 + n, i + n], 1)], 0)
+        parts.append((verts, faces))
+    return _merge(parts)
+
+
+def _leaf_cards(rs, centres, radii, count, size):
+    """`count` two-triangle leaf cards with random orientation, scattered in ellipsoidal crowns (centres [k,3], radii [k,3])."""
+    k = rs.randint(0, centres.shape[0], count)
+    d = rs.standard_normal((count, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rad = rs.random_sample(count) ** (1.0 / 3.0)
+    c = centres[k] + d * rad[:, None] * radii[k]
+    a = rs.standard_normal((count, 3))
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = np.cross(a, rs.standard_normal((count, 3)))
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    s = size * (0.6 + 0.8 * rs.random_sample(count))[:, None]
+    quad = np.stack([c - a * s - b * s * 0.5, c + a * s - b * s * 0.5, c + a * s + b * s * 0.5, c - a * s + b * s * 0.5], 1)
+    verts = quad.reshape(-1, 3)
+    base = 4 * np.arange(count)[:, None]
+    faces = np.concatenate([base + np.array([[0, 1, 2]]), base + np.array([[0, 2, 3]])], 1).reshape(-1, 3)
+    return verts, faces
+
+
+def courtyard(seed=4):
+    """San-Miguel-class stand-in: an arcaded courtyard (two storeys of columns and arches on four sides, recessed walls,
+    a tiled floor) with trees whose crowns are hundreds of thousands of randomly oriented leaf cards, thin branches,
+    tables and chairs: 999 9xx triangles (full-SAH builder branch).  Shadow rays from the floor and the furniture cross
+    the crowns towards a high light, so most rays walk long paths between near misses -- the tail of the frame, not
+    the average, sets the time."""
+    rs = np.random.RandomState(seed)
+    size, storey = 60.0, 6.0
+    parts = []
+    fv, ff = _grid([0, 0, 0], [size, 0, 0], [0, 0, size], 150, 150)                # floor 45 000
+    fv[:, 1] = 0.05 * _value_noise(fv[:, 0] / 2.0, fv[:, 2] / 2.0, seed, 48)
+    parts.append((fv, ff))
+    inset, ncol = 6.0, 11
+    cols = np.linspace(inset, size - inset, ncol)
+    ring = [(x, inset) for x in cols] + [(size - inset, z) for z in cols[1:]] + \
+           [(x, size - inset) for x in cols[-2::-1]] + [(inset, z) for z in cols[-2:0:-1]]
+    for level in range(2):                                                        # columns 40 x 2 x 768, arches 40 x 2 x 96
+        y0 = level * storey
+        for k, (x, z) in enumerate(ring):
+            parts.append(_tube([x, y0, z], [x, y0 + storey * 0.7, z], 0.32, 0.26, 24, 16))
+            nx, nz = ring[(k + 1) % len(ring)]
+            parts.append(_arch([x, z], [nx, nz], y0 + storey * 0.7, storey * 0.28, 0.6, 0.25, 24))
+        # gallery slab above the arcade, between the column ring and the outer wall
+        for (o, du, dv) in (([0, y0 + storey, 0], [size, 0, 0], [0, 0, inset]), ([0, y0 + storey, size - inset], [size, 0, 0], [0, 0, inset]),
+                            ([0, y0 + storey, inset], [inset, 0, 0], [0, 0, size - 2 * inset]),
+                            ([size - inset, y0 + storey, inset], [inset, 0, 0], [0, 0, size - 2 * inset])):
+            parts.append(_grid(o, du, dv, 40, 8))
+    h = 2 * storey + 1.5                                                          # outer walls with a relief
+    for (o, du, dv) in (([0, 0, 0], [size, 0, 0], [0, h, 0]), ([0, 0, size], [0, h, 0], [size, 0, 0]),
+                        ([0, 0, 0], [0, h, 0], [0, 0, size]), ([size, 0, 0], [0, 0, size], [0, h, 0])):
+        wv, wf = _grid(o, du, dv, 120, 28)
+        n = np.cross(du, dv)
+        n = n / np.linalg.norm(n)
+        wv += n[None, :] * (0.15 * _value_noise(wv[:, 0] + wv[:, 2], wv[:, 1] * 1.7, seed + 2, 64))[:, None]
+        parts.append((wv, wf))
+    # trees: trunk, branches, crowns of leaf cards
+    ntree = 9
+    tx = np.stack([14 + 16 * (np.arange(ntree) % 3) + rs.random_sample(ntree) * 3,
+                   14 + 16 * (np.arange(ntree) // 3) + rs.random_sample(ntree) * 3], 1)
+    crowns_c, crowns_r = [], []
+    for t in range(ntree):
+        x, z = tx[t]
+        top = 4.0 + rs.random_sample() * 1.5
+        parts.append(_tube([x, 0, z], [x, top, z], 0.35, 0.22, 16, 12))
+        for b in range(28):
+            d = rs.standard_normal(3)
+            d[1] = abs(d[1]) * 0.8 + 0.3
+            d /= np.linalg.norm(d)
+            start = np.array([x, top * (0.55 + 0.45 * rs.random_sample()), z])
+            end = start + d * (2.0 + 2.5 * rs.random_sample())
+            parts.append(_tube(start, end, 0.09, 0.03, 8, 6))
+            crowns_c.append(end)
+            crowns_r.append([1.0 + rs.random_sample(), 0.7 + 0.6 * rs.random_sample(), 1.0 + rs.random_sample()])
+    # furniture: tables (5 boxes) and chairs (6 boxes)
+    m = 150
+    c = np.stack([rs.random_sample(m) * (size - 2 * inset - 6) + inset + 3, np.zeros(m), rs.random_sample(m) * (size - 2 * inset - 6) + inset + 3], 1)
+    lo, hi = [], []
+    for k in range(m):
+        w, d_, hh = (1.2, 0.8, 0.75) if k % 3 == 0 else (0.45, 0.45, 0.45)
+        lo.append(c[k] + [-w / 2, hh - 0.05, -d_ / 2]); hi.append(c[k] + [w / 2, hh, d_ / 2])          # top / seat
+        for sx in (-1, 1):
+            for sz in (-1, 1):
+                p = c[k] + [sx * (w / 2 - 0.04), 0, sz * (d_ / 2 - 0.04)]
+                lo.append(p - [0.03, 0, 0.03]); hi.append(p + [0.03, hh - 0.05, 0.03])
+        if k % 3:
+            lo.append(c[k] + [-w / 2, hh, -d_ / 2]); hi.append(c[k] + [w / 2, hh + 0.5, -d_ / 2 + 0.04])  # chair back
+    parts.append(_boxes_fast(np.array(lo), np.array(hi)))
+    v, f = _merge(parts)
+    leaves = (999990 - f.shape[0]) // 2                                           # fill the budget with leaf cards
+    parts.append(_leaf_cards(rs, np.array(crowns_c), np.array(crowns_r), leaves, 0.09))
+    v, f = _merge([(v, f), parts[-1]])
+    sc = _finish("courtyard", v, f, light_point=[size * 0.62, 55.0, size * 0.35])
+    sc.eye = np.array([9.0, 1.7, 11.0], np.float32)                               # a visitor under the arcade corner
+    sc.target = np.array([38.0, 3.2, 36.0], np.float32)
+    return sc
+
+
 def terrain(n=23, seed=7):
     """Small sin-free bumpy grid with many equal centroids per axis (sort-tie stress): 2*n*n tris."""
     v, f = _grid([0, 0, 0], [float(n), 0, 0], [0, 0, float(n)], n, n)
@@ -203,7 +346,8 @@ def calib(seed=0):
     return sc
 
 
-SCENES = {"cornell": cornell, "atrium": atrium, "city": city, "city_big": city_big, "calib": calib}
+SCENES = {"cornell": cornell, "atrium": atrium, "city": city, "city_big": city_big, "calib": calib,
+          "courtyard": courtyard}
 
 
 # ------------------------------------------------------------------------------------------------

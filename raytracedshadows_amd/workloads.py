@@ -17,6 +17,8 @@ CONFIGS = {
     "atrium_1080p": ("atrium", 1920, 1080, "point", 1),       # configs[1]
     "city_4k": ("city", 3840, 2160, "point", 1),              # configs[2]  (headline; [3] = same, striped)
     "city_4k_soft16": ("city", 3840, 2160, "point", 16),      # configs[4]
+    "courtyard_4k": ("courtyard", 3840, 2160, "point", 1),    # configs[2] on the San-Miguel-class stand-in (hard case)
+    "courtyard_4k_soft16": ("courtyard", 3840, 2160, "point", 16),
     "calib_4k": ("calib", 3840, 2160, "point", 1),            # counter calibration only (see scenes.calib)
 }
 

@@ -86,6 +86,31 @@ def test_config2_city_4k_full_size(ctx, city4k):
     assert 0.2 < want.mean() < 0.8                                                # a real mix of lit / occluded
 
 
+def test_config2_courtyard_4k_full_size_hard_scene(ctx):
+    """BASELINE configs[2] on the San-Miguel-class stand-in (arcades, nine trees of ~400 000 leaf cards, furniture;
+    999 990 triangles): ~60 nodes per ray, rays that scatter between leaves -- packets dissolve, waves run long.
+    Every kernel variant at 3840x2160, then 2- and 8-way interleaved stripes with the default kernel."""
+    wl = workloads.prepare_config("courtyard_4k")
+    want = _check_workload(ctx, wl)
+    assert 0.2 < want.mean() < 0.8
+    W, H = wl.W, wl.H
+    ctx.set_option("kernel", -1)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        for n in (2, 8):
+            got = np.full((H, W), 9, np.uint8)
+            ctx.h2d(d_mask, got)
+            for r in range(n):
+                ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, r, light=wl.light)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            assert (got == want).all(), n
+    finally:
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
 def test_config3_city_4k_row_striped_2_4_8(ctx, city4k):
     """BASELINE configs[3] at its own workload: the 3840x2160 frame of the ~1M-triangle scene cut into 2/4/8 row
     stripes, default kernel (the packet kernel), both partitions the multi-GPU path offers -- contiguous
@@ -531,6 +556,38 @@ def test_gbuffer_pass_on_the_gpu_is_bit_identical_to_the_oracle(ctx, scene, W, H
     finally:
         ctx.free(d_pos)
         ctx.free(d_nrm)
+
+
+def test_whole_frame_on_the_device_gbuffer_mask_combine_and_blob(ctx, tmp_path):
+    """SURVEY.md 8 f4 on the GPU: G-buffer -> shadow mask -> combine pass (Combine.frag:18-37) without leaving the device,
+    against the host combine of the oracle's mask; the packed stream goes through the blob file (save/load) first.
+    Point light, 16-sample soft shadows and the reference's directional light."""
+    wl = workloads.prepare("atrium", 640, 360)
+    W, H, sc = wl.W, wl.H, wl.scene
+    blob = api.load_bvh(api.save_bvh(str(tmp_path / "atrium.bvh"), wl.packed))
+    assert (blob == wl.packed).all()
+    ctx.set_bvh(blob)
+    ctx.set_option("kernel", -1)
+    pos, nrm, _ = oracle.primary_gbuffer(wl.packed, sc.eye, sc.target, sc.fovy, W, H)
+    d_pos, d_nrm, d_mask, d_rgb = ctx.malloc(pos.nbytes), ctx.malloc(nrm.nbytes), ctx.malloc(W * H), ctx.malloc(W * H * 3)
+    try:
+        api.primary_gbuffer_device(ctx, sc.eye, sc.target, sc.fovy, W, H, d_pos, d_nrm)
+        for light in (wl.light, workloads.relight(wl, "point", 16).light, None):
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=light)
+            api.combine_device(ctx, wl.constants, light, d_pos, d_nrm, d_mask, W, H, d_rgb)
+            ctx.synchronize()
+            got = np.zeros((H, W, 3), np.uint8)
+            ctx.d2h(got, d_rgb)
+            mask, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(light, wl.constants),
+                                            pos, W, H)
+            want = api.combine(wl.constants, light, pos, nrm, mask)
+            assert (got == want).all(), f"{(got != want).any(axis=2).sum()} pixels differ"
+            assert want.max() > 100 and (want[nrm[..., :3].any(axis=2)] >= int(0.15 * 255)).all()
+        with pytest.raises(api.RtsError):
+            api.combine_device(ctx, wl.constants, wl.light, None, d_nrm, d_mask, W, H, d_rgb)   # point light needs positions
+    finally:
+        for d in (d_pos, d_nrm, d_mask, d_rgb):
+            ctx.free(d)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))

@@ -10,6 +10,7 @@ def test_scene_triangle_counts():
     assert scenes.cornell().triangle_count == 1024
     assert scenes.atrium().triangle_count == 249996
     assert scenes.terrain(23).triangle_count == 1058
+    assert scenes.courtyard().triangle_count == 999990              # <= 1 000 000: the builder's full-SAH branch
 
 
 def test_scenes_are_deterministic():

@@ -33,9 +33,11 @@ def main():
         ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
         ctx.synchronize()
         print(f"G-buffer + shadow mask on the GPU: {(time.time() - t0) * 1e3:.2f} ms (first call, incl. launch)")
-        pos, nrm, mask = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.uint8)
-        ctx.d2h(pos, d_pos); ctx.d2h(nrm, d_nrm); ctx.d2h(mask, d_mask)
-    rgb = api.combine(wl.constants, wl.light, pos, nrm, mask)
+        d_rgb = ctx.malloc(W * H * 3)
+        api.combine_device(ctx, wl.constants, wl.light, d_pos, d_nrm, d_mask, W, H, d_rgb)     # the frame stays on the device
+        ctx.synchronize()
+        rgb, mask = np.zeros((H, W, 3), np.uint8), np.zeros((H, W), np.uint8)
+        ctx.d2h(rgb, d_rgb); ctx.d2h(mask, d_mask)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     api.write_ppm(args.out, rgb)
     print(f"wrote {args.out}: {W}x{H}, lit fraction {float((mask > 0).mean()):.3f}")
