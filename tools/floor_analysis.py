@@ -72,6 +72,19 @@ def main():
                       f"waves in flight avg {in_flight:.0f} of 8192; first 8192 waves started within {fill_us:.2f} us "
                       f"({(k + 1) / max(fill_us, 1e-9):.0f} waves/us), then {steady:.0f} waves/us; "
                       f"waves per XCC {np.bincount(xcc.astype(np.int64), minlength=8).tolist()}", flush=True)
+                # timeline: waves in flight in 20 equal slices of the kernel, and where the waves that end last sit
+                t0, t1 = (r0 - r0.min()) / 100.0, (r1 - r0.min()) / 100.0
+                edges = np.linspace(0.0, span_us, 21)
+                mid = (edges[:-1] + edges[1:]) / 2
+                infl = [int(((t0 <= m) & (t1 > m)).sum()) for m in mid]
+                print("    in flight per 5% slice: " + " ".join(str(v) for v in infl))
+                late = t1 > 0.85 * span_us
+                ty = ((st[ok, 3] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
+                rows = ty[late]
+                print(f"    waves ending in the last 15%: {late.sum()}, started at {np.percentile(t0[late], [0, 50, 100]).round(1).tolist()} us, "
+                      f"lifetime {np.percentile((t1 - t0)[late], [0, 50, 100]).round(1).tolist()} us, tile rows {np.percentile(rows, [0, 50, 100]).tolist()} of {ty.max() + 1}")
+                cost_by_band = [float((t1 - t0)[(ty >= a) & (ty < a + 27)].mean()) for a in range(0, int(ty.max()) + 1, 27)]
+                print("    mean lifetime (us) per band of 27 tile rows, top to bottom: " + " ".join(f"{c:.1f}" for c in cost_by_band))
         ctx.free(d_pos)
         ctx.free(d_mask)
 
