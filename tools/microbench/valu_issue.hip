@@ -1,81 +1,138 @@
-// Microbenchmark (GPU box): sustained wave64 instruction issue per SIMD on gfx950 for the instruction mix of the
-// packet loop.  Build: hipcc --offload-arch=gfx950 -O2 -o valu_issue valu_issue.hip ; run: ./valu_issue
+// Microbenchmark (GPU box): sustained wave64 instruction issue per SIMD on gfx950, measured in SHADER CLOCKS.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o valu_issue valu_issue.hip && ./valu_issue
+//
+// Method (round 2; replaces the wall-clock version whose first data point was taken on a cold clock):
+//   * every wave stamps s_memtime (shader cycles) around its loop; the figure of a run is
+//       instructions per clock per SIMD = waves_per_SIMD x instructions_per_wave / median(cycles per wave)
+//     so no clock frequency is assumed anywhere; s_memrealtime (100 MHz) beside it gives the clock that was held;
+//   * grid = 1024 SIMDs x waves_per_SIMD one-wave workgroups, all co-resident, each loop ~1 ms long (launch skew of a
+//     few microseconds is < 1 %);
+//   * 1.5 s of back-to-back launches of the same kernel before the measured one (clock and power state settled).
+// Modes:
+//   fma      16 independent v_fma_f32 per iteration                     -- calibration: the guide's 0.5 / clk / SIMD
+//   slab     the packet loop's ordered slab test, 16 VALU (6 v_sub with an SGPR operand, 6 v_mul, v_min3, v_max,
+//            v_max3, v_cmp_ge into an SGPR pair), no scalar work
+//   step     slab + the scalar side of a down-step of the real loop: s_add, s_load_dwordx8 of a 32-byte node (always
+//            the same few nodes: scalar-cache hits), s_waitcnt, s_cmp, s_cbranch, s_andn2, s_cbranch (7 scalar)
+//   stepmiss step with the node address striding through a 64 MB table (scalar-cache and mostly L2 misses)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 
-// MODE 0: 16 independent v_mul/v_sub/v_min3 (no memory).  MODE 1: the same + 9 SALU + 1 taken branch per 16 VALU.
+#define SLAB16(O, I)                                                                                                     \
+    "v_sub_f32 %[t0], s44, %[" O "x]\n\t v_sub_f32 %[t1], s45, %[" O "y]\n\t v_sub_f32 %[t2], s46, %[" O "z]\n\t"        \
+    "v_sub_f32 %[t3], s40, %[" O "x]\n\t v_sub_f32 %[t4], s41, %[" O "y]\n\t v_sub_f32 %[t5], s42, %[" O "z]\n\t"        \
+    "v_mul_f32 %[t0], %[t0], %[" I "x]\n\t v_mul_f32 %[t1], %[t1], %[" I "y]\n\t v_mul_f32 %[t2], %[t2], %[" I "z]\n\t"  \
+    "v_mul_f32 %[t3], %[t3], %[" I "x]\n\t v_mul_f32 %[t4], %[t4], %[" I "y]\n\t v_mul_f32 %[t5], %[t5], %[" I "z]\n\t"  \
+    "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t v_max_f32 %[t3], %[t3], %[t4]\n\t v_max3_f32 %[t3], %[t3], %[t5], 0\n\t"  \
+    "v_cmp_ge_f32 s[54:55], %[t0], %[t3]\n\t"
+
+enum { FMA = 0, SLAB = 1, STEP = 2, STEPMISS = 3 };
+
 template <int MODE>
-__global__ __launch_bounds__(64) void spin(float* out, int iters) {
-    float a = threadIdx.x * 1e-3f + 1.0f, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f, e = a * 0.3f, f = a * 0.7f;
-    unsigned s0 = blockIdx.x, s1 = 3, s2 = 5;
+__global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int iters, unsigned long long* stamps, float* sink) {
+    float ox = threadIdx.x * 1e-3f + 0.1f, oy = ox + 0.2f, oz = ox + 0.3f, ix = 1.5f, iy = 2.5f, iz = 3.5f;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    float a[16];
+    for (int k = 0; k < 16; ++k) a[k] = ox + k;
+    unsigned long long members = ~0ull;
+    unsigned off = (blockIdx.x * 2654435761u) & mask & ~31u;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
-        asm volatile(
-            "v_sub_f32 %0, 0x3f800000, %0\n\t v_sub_f32 %1, 0x3f800000, %1\n\t v_sub_f32 %2, 0x3f800000, %2\n\t"
-            "v_sub_f32 %3, 0x3f800000, %3\n\t v_sub_f32 %4, 0x3f800000, %4\n\t v_sub_f32 %5, 0x3f800000, %5\n\t"
-            "v_mul_f32 %0, %0, %1\n\t v_mul_f32 %2, %2, %3\n\t v_mul_f32 %4, %4, %5\n\t"
-            "v_mul_f32 %1, %1, %2\n\t v_mul_f32 %3, %3, %4\n\t v_mul_f32 %5, %5, %0\n\t"
-            "v_min3_f32 %0, %0, %1, %2\n\t v_max_f32 %3, %3, %4\n\t v_max3_f32 %3, %3, %5, 0\n\t"
-            "v_cmp_ge_f32 vcc, %0, %3\n\t"
-            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "vcc");
-        if (MODE == 1)
+        if (MODE == FMA) {
             asm volatile(
-                "s_add_u32 %0, %0, 32\n\t s_and_b64 vcc, vcc, exec\n\t s_cmp_lg_u32 %1, -1\n\t s_add_u32 %1, %1, 1\n\t"
-                "s_andn2_b64 vcc, exec, vcc\n\t s_lshl_b32 %2, %0, 5\n\t s_sub_u32 %2, %2, 1\n\t s_cmp_eq_u32 %2, -1\n\t"
-                "s_and_b64 vcc, vcc, exec\n\t"
-                : "+s"(s0), "+s"(s1), "+s"(s2) : : "vcc", "scc");
+                "v_fma_f32 %0, %0, %16, %0\n\t v_fma_f32 %1, %1, %16, %1\n\t v_fma_f32 %2, %2, %16, %2\n\t v_fma_f32 %3, %3, %16, %3\n\t"
+                "v_fma_f32 %4, %4, %16, %4\n\t v_fma_f32 %5, %5, %16, %5\n\t v_fma_f32 %6, %6, %16, %6\n\t v_fma_f32 %7, %7, %16, %7\n\t"
+                "v_fma_f32 %8, %8, %16, %8\n\t v_fma_f32 %9, %9, %16, %9\n\t v_fma_f32 %10, %10, %16, %10\n\t v_fma_f32 %11, %11, %16, %11\n\t"
+                "v_fma_f32 %12, %12, %16, %12\n\t v_fma_f32 %13, %13, %16, %13\n\t v_fma_f32 %14, %14, %16, %14\n\t v_fma_f32 %15, %15, %16, %15\n\t"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                  "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                : "v"(ix));
+        } else if (MODE == SLAB) {
+            asm volatile(SLAB16("o", "i")
+                         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)
+                         : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz)
+                         : "s40", "s41", "s42", "s44", "s45", "s46", "s54", "s55");
+        } else {
+            // one down-step of the packet loop (tools/gen_packet_asm.py, loop_leaf): node fetch, leaf check, slab test,
+            // "nobody leaves" check.  The node never is a leaf and every lane always hits (boxes of +-1e30).
+            asm volatile(
+                "s_add_u32 %[off], %[off], %[stride]\n\t"
+                "s_and_b32 %[off], %[off], %[mask]\n\t"
+                "s_load_dwordx8 s[40:47], %[base], %[off]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_cmp_lg_u32 s43, -1\n\t"
+                "s_cbranch_scc1 9f\n\t"
+                SLAB16("o", "i")
+                "s_andn2_b64 s[50:51], %[m], s[54:55]\n\t"
+                "s_cbranch_scc0 9f\n\t"
+                "s_mov_b64 %[m], -1\n\t"
+                "9:\n\t"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [off] "+s"(off), [m] "+s"(members)
+                : [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [base] "s"(nodes),
+                  [stride] "s"(MODE == STEPMISS ? 0x9E3780u : 32u), [mask] "s"(mask & ~31u)
+                : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s54", "s55", "scc");
+        }
     }
-    if (a + b + c + d + e + f + (float)(s0 + s1 + s2) == 123.456f) out[0] = a;
-}
-
-// MODE 2: the same slab test with packed f32: 4 v_pk_add + 4 v_pk_mul instead of 6 v_sub + 6 v_mul (12 VALU / iter).
-__global__ __launch_bounds__(64) void spinPk(float* out, int iters) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 a = { threadIdx.x * 1e-3f + 1.0f, 2.0f }, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f, o = a * 0.3f, iv = a * 0.7f;
-    for (int i = 0; i < iters; ++i) {
-        asm volatile(
-            "v_pk_add_f32 %0, %0, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t v_pk_add_f32 %1, %1, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_add_f32 %2, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t v_pk_add_f32 %3, %3, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_mul_f32 %0, %0, %5\n\t v_pk_mul_f32 %1, %1, %5\n\t v_pk_mul_f32 %2, %2, %5\n\t v_pk_mul_f32 %3, %3, %5\n\t"
-            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(o), "v"(iv));
-        asm volatile(
-            "v_min3_f32 %0, %0, %1, %2\n\t v_max_f32 %3, %3, %4\n\t v_max3_f32 %3, %3, %5, 0\n\t v_cmp_ge_f32 vcc, %0, %3\n\t"
-            : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(c.x), "+v"(c.y), "+v"(d.x) : : "vcc");
-    }
-    if (a.x + b.x + c.x + d.x + a.y == 123.456f) out[0] = a.x;
-}
-
-static void runPk(int wavesPerSimd, float* d_out) {
-    const int iters = 20000, waves = 256 * 4 * wavesPerSimd;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(spinPk, dim3(waves), dim3(64), 0, 0, d_out, 100);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(spinPk, dim3(waves), dim3(64), 0, 0, d_out, iters);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double simdCycles = ms * 1e-3 * 2.4e9 * 1024;
-    printf("8 v_pk + 4 VALU / iter        %d waves/SIMD: %.3f ms  -> %.3f slab tests per clk per SIMD (16-VALU form: see above x 1/16)\n",
-           wavesPerSimd, ms, (double)iters * waves / simdCycles);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = c1 - c0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+    float s = t0 + t3 + (float)members;
+    for (int k = 0; k < 16; ++k) s += a[k];
+    if (s == 123.456f) sink[0] = s;
 }
 
 template <int MODE>
-static void run(const char* name, int wavesPerSimd, float* d_out) {
-    const int iters = 20000, waves = 256 * 4 * wavesPerSimd;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, d_out, 100);
+static void run(const char* name, int wavesPerSimd, int valuPerIter, int scalarPerIter, const void* nodes, unsigned mask,
+                unsigned long long* d_stamps, float* d_sink, int cus) {
+    const int waves = cus * 4 * wavesPerSimd;
+    const int iters = MODE == STEPMISS ? 4000 : 40000 / wavesPerSimd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, d_out, iters);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double valu = 16.0 * iters * waves, other = (MODE == 1 ? 9.0 : 0.0) * iters * waves + 3.0 * iters * waves;  // + loop ctrl
-    const double simdCycles = ms * 1e-3 * 2.4e9 * 1024;
-    printf("%-28s %d waves/SIMD: %.3f ms  VALU %.3f per clk per SIMD (at 2.4 GHz), all instr %.3f per clk per SIMD\n", name,
-           wavesPerSimd, ms, valu / simdCycles, (valu + other) / simdCycles);
+    float ms = 0;
+    do {                                                        // warm-up: at least 1.5 s of the same work
+        for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, nodes, mask, iters, d_stamps, d_sink);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    } while (ms < 1500.f);
+    hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, nodes, mask, iters, d_stamps, d_sink);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> st(waves * 2);
+    hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc(waves), mhz(waves);
+    for (int w = 0; w < waves; ++w) { cyc[w] = (double)st[2 * w]; mhz[w] = (double)st[2 * w] / (double)st[2 * w + 1] * 100.0; }
+    std::sort(cyc.begin(), cyc.end()); std::sort(mhz.begin(), mhz.end());
+    const double med = cyc[waves / 2];
+    printf("%-9s %d waves/SIMD: %8.0f clk per wave (p5 %.0f p95 %.0f) for %d iterations -> %.1f clk per iteration per wave; "
+           "VALU %.3f / clk / SIMD, all instr %.3f / clk / SIMD; clock %.0f MHz\n",
+           name, wavesPerSimd, med, cyc[waves / 20], cyc[waves - 1 - waves / 20], iters, med / iters,
+           (double)wavesPerSimd * valuPerIter * iters / med, (double)wavesPerSimd * (valuPerIter + scalarPerIter + 3) * iters / med,
+           mhz[waves / 2]);
+    fflush(stdout);
 }
 
 int main() {
-    float* d_out; hipMalloc(&d_out, 64);
-    for (int w : {1, 2, 4, 8}) run<0>("16 VALU / iter", w, d_out);
-    for (int w : {1, 2, 4, 8}) run<1>("16 VALU + 9 SALU / iter", w, d_out);
-    for (int w : {2, 4, 8}) runPk(w, d_out);
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const size_t bytes = 64u << 20;
+    std::vector<unsigned> host(bytes / 4);
+    for (size_t n = 0; n < bytes / 32; ++n) {                    // inner nodes whose box every ray hits
+        float lo = -1e30f, hi = 1e30f;
+        unsigned* w = &host[n * 8];
+        for (int k = 0; k < 3; ++k) { memcpy(&w[k], &lo, 4); memcpy(&w[4 + k], &hi, 4); }
+        w[3] = 0xFFFFFFFFu; w[7] = 0xFFFFFFFFu;
+    }
+    void* d_nodes; hipMalloc(&d_nodes, bytes); hipMemcpy(d_nodes, host.data(), bytes, hipMemcpyHostToDevice);
+    unsigned long long* d_stamps; hipMalloc(&d_stamps, (size_t)cus * 4 * 8 * 2 * 8);
+    float* d_sink; hipMalloc(&d_sink, 64);
+    printf("%s, %d CUs\n", prop.name, cus);
+    for (int w : {1, 2, 4, 8}) run<FMA>("fma", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
+    for (int w : {1, 2, 4, 8}) run<SLAB>("slab", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
+    for (int w : {1, 2, 4, 8}) run<STEP>("step", w, 16, 9, d_nodes, 1023u, d_stamps, d_sink, cus);          // 1 KB of nodes: K$ hits
+    for (int w : {4, 8}) run<STEPMISS>("stepmiss", w, 16, 9, d_nodes, (unsigned)(bytes - 1), d_stamps, d_sink, cus);
     return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the same counters for several option sets of one config.  usage: tools/pmc_ab.sh <outdir> <config> "<counters>" "<opts A>" "<opts B>" ...
 set -u
-OUT=$1; CFG=$2; PMC=$3; shift 3
+OUT=$(realpath -m $1); CFG=$2; PMC=$3; shift 3
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
