@@ -2,12 +2,14 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -o valu_issue valu_issue.hip && ./valu_issue
 //
-// Method (round 2; replaces the wall-clock version whose first data point was taken on a cold clock):
-//   * every wave stamps s_memtime (shader cycles) around its loop; the figure of a run is
-//       instructions per clock per SIMD = waves_per_SIMD x instructions_per_wave / median(cycles per wave)
-//     so no clock frequency is assumed anywhere; s_memrealtime (100 MHz) beside it gives the clock that was held;
-//   * grid = 1024 SIMDs x waves_per_SIMD one-wave workgroups, all co-resident, each loop ~1 ms long (launch skew of a
-//     few microseconds is < 1 %);
+// Method (round 2; replaces the wall-clock version that assumed 2.4 GHz):
+//   * every wave stamps s_memtime (shader cycles) and s_memrealtime (the chip-wide 100 MHz counter) around its loop.
+//     clock held = sum(shader cycles) / sum(realtime ticks) x 100 MHz; span of the launch = last end - first start on the
+//     realtime counter, converted to shader cycles with that clock;
+//       instructions per clock per SIMD = waves x iterations x instructions per iteration / (span cycles x SIMDs)
+//     so the chip-wide rate is measured, whatever the placement of the waves, and no clock frequency is assumed;
+//   * the grid holds 16 x as many one-wave workgroups as fit at once (like the real launch, slots are refilled as waves
+//     end); occupancy is set with dynamic LDS: 160 KB per CU / (4 x waves per SIMD) workgroups;
 //   * 1.5 s of back-to-back launches of the same kernel before the measured one (clock and power state settled).
 // Modes:
 //   fma      16 independent v_fma_f32 per iteration                     -- calibration: the guide's 0.5 / clk / SIMD
@@ -35,6 +37,7 @@ enum { FMA = 0, SLAB = 1, STEP = 2, STEPMISS = 3 };
 
 template <int MODE>
 __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int iters, unsigned long long* stamps, float* sink) {
+    extern __shared__ unsigned char occupancyPad[];     // never touched: sets the number of workgroups per CU
     float ox = threadIdx.x * 1e-3f + 0.1f, oy = ox + 0.2f, oz = ox + 0.3f, ix = 1.5f, iy = 2.5f, iz = 3.5f;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     float a[16];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = c1 - c0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+    if (threadIdx.x == 0) { stamps[blockIdx.x * 3] = c1 - c0; stamps[blockIdx.x * 3 + 1] = r0; stamps[blockIdx.x * 3 + 2] = r1; }
     float s = t0 + t3 + (float)members;
     for (int k = 0; k < 16; ++k) s += a[k];
     if (s == 123.456f) sink[0] = s;
@@ -88,30 +91,43 @@ __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int
 template <int MODE>
 static void run(const char* name, int wavesPerSimd, int valuPerIter, int scalarPerIter, const void* nodes, unsigned mask,
                 unsigned long long* d_stamps, float* d_sink, int cus) {
-    const int waves = cus * 4 * wavesPerSimd;
-    const int iters = MODE == STEPMISS ? 4000 : 40000 / wavesPerSimd;
+    const int over = 16;
+    const int waves = cus * 4 * wavesPerSimd * over;
+    const int iters = (MODE == STEPMISS ? 4000 : 40000) / wavesPerSimd / over;
+    // occupancy limit through LDS: 4 x wavesPerSimd workgroups per CU (8 per SIMD is the hardware's own limit)
+    const size_t lds = wavesPerSimd >= 8 ? 0 : (size_t)(160 * 1024) / (4 * wavesPerSimd + 1) + 1024;
+    hipFuncSetAttribute((const void*)spin<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     float ms = 0;
     do {                                                        // warm-up: at least 1.5 s of the same work
-        for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, nodes, mask, iters, d_stamps, d_sink);
+        for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), lds, 0, nodes, mask, iters, d_stamps, d_sink);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     } while (ms < 1500.f);
-    hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), 0, 0, nodes, mask, iters, d_stamps, d_sink);
+    hipLaunchKernelGGL(spin<MODE>, dim3(waves), dim3(64), lds, 0, nodes, mask, iters, d_stamps, d_sink);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> st(waves * 2);
+    std::vector<unsigned long long> st((size_t)waves * 3);
     hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
-    std::vector<double> cyc(waves), mhz(waves);
-    for (int w = 0; w < waves; ++w) { cyc[w] = (double)st[2 * w]; mhz[w] = (double)st[2 * w] / (double)st[2 * w + 1] * 100.0; }
-    std::sort(cyc.begin(), cyc.end()); std::sort(mhz.begin(), mhz.end());
-    const double med = cyc[waves / 2];
-    printf("%-9s %d waves/SIMD: %8.0f clk per wave (p5 %.0f p95 %.0f) for %d iterations -> %.1f clk per iteration per wave; "
-           "VALU %.3f / clk / SIMD, all instr %.3f / clk / SIMD; clock %.0f MHz\n",
-           name, wavesPerSimd, med, cyc[waves / 20], cyc[waves - 1 - waves / 20], iters, med / iters,
-           (double)wavesPerSimd * valuPerIter * iters / med, (double)wavesPerSimd * (valuPerIter + scalarPerIter + 3) * iters / med,
-           mhz[waves / 2]);
+    double cyc = 0, ticks = 0;
+    unsigned long long first = ~0ull, last = 0;
+    std::vector<double> per(waves);
+    for (int w = 0; w < waves; ++w) {
+        cyc += (double)st[3 * w]; ticks += (double)(st[3 * w + 2] - st[3 * w + 1]);
+        first = std::min(first, st[3 * w + 1]); last = std::max(last, st[3 * w + 2]);
+        per[w] = (double)st[3 * w] / iters;
+    }
+    std::sort(per.begin(), per.end());
+    const double mhz = cyc / ticks * 100.0;
+    const double spanCycles = (double)(last - first) * mhz / 100.0;
+    const double inFlight = ticks / (double)(last - first);
+    const double simds = cus * 4.0;
+    printf("%-9s %d waves/SIMD: %6.1f clk per iteration per wave (p5 %.1f p95 %.1f); waves in flight %.0f of %d; "
+           "VALU %.3f / clk / SIMD, all instr %.3f / clk / SIMD; clock %.0f MHz; span %.0f us\n",
+           name, wavesPerSimd, per[waves / 2], per[waves / 20], per[waves - 1 - waves / 20], inFlight, cus * 4 * wavesPerSimd,
+           (double)waves * valuPerIter * iters / (spanCycles * simds),
+           (double)waves * (valuPerIter + scalarPerIter + 3) * iters / (spanCycles * simds), mhz, (double)(last - first) / 100.0);
     fflush(stdout);
 }
 
@@ -128,7 +144,7 @@ int main() {
         w[3] = 0xFFFFFFFFu; w[7] = 0xFFFFFFFFu;
     }
     void* d_nodes; hipMalloc(&d_nodes, bytes); hipMemcpy(d_nodes, host.data(), bytes, hipMemcpyHostToDevice);
-    unsigned long long* d_stamps; hipMalloc(&d_stamps, (size_t)cus * 4 * 8 * 2 * 8);
+    unsigned long long* d_stamps; hipMalloc(&d_stamps, (size_t)cus * 4 * 8 * 16 * 3 * 8);
     float* d_sink; hipMalloc(&d_sink, 64);
     printf("%s, %d CUs\n", prop.name, cus);
     for (int w : {1, 2, 4, 8}) run<FMA>("fma", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
