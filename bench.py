@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the dispatch-floor and shader-clock probes (profiler runs: only the timed kernel is launched)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -351,26 +353,28 @@ def main():
     median_ms = float(np.median(per_launch))
 
     # ---- the same dispatch against a one-triangle BVH: what the frame costs before any traversal ----------------
-    tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
-    floor_ctx = api.ShadowContext(device)
-    floor_ctx.set_bvh(api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes)
-    if args.kernel >= 0:
-        floor_ctx.set_option("kernel", args.kernel)
-    for _ in range(20):
-        one_step(floor_ctx)
-    fl = []
-    for i in range(30):
-        floor_ctx.timer_mark(0)
-        one_step(floor_ctx)
-        floor_ctx.timer_mark(1)
-        fl.append(floor_ctx.timer_between_ms(0, 1))
-    floor_ms = float(np.median(fl))
-    floor_ctx.close()
-    ctx.h2d(d_mask, got)                                            # (the floor frames overwrote the mask)
+    floor_ms = float("nan")
+    if not args.no_probes:
+        tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
+        floor_ctx = api.ShadowContext(device)
+        floor_ctx.set_bvh(api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes)
+        if args.kernel >= 0:
+            floor_ctx.set_option("kernel", args.kernel)
+        for _ in range(20):
+            one_step(floor_ctx)
+        fl = []
+        for i in range(30):
+            floor_ctx.timer_mark(0)
+            one_step(floor_ctx)
+            floor_ctx.timer_mark(1)
+            fl.append(floor_ctx.timer_between_ms(0, 1))
+        floor_ms = float(np.median(fl))
+        floor_ctx.close()
+        ctx.h2d(d_mask, got)                                        # (the floor frames overwrote the mask)
 
     # ---- shader clock held under this load (diagnostics build of the same kernel, after the timed region) --------
     clock_mhz = None
-    if kname.startswith("shadowMaskPacketKernel") and not striped:
+    if kname.startswith("shadowMaskPacketKernel") and not striped and not args.no_probes:
         try:
             for _ in range(50):
                 one_step()
@@ -405,12 +409,12 @@ def main():
                    "rays_per_frame": rays_per_frame, "kernel": kname, "bvh_bytes": int(wl.packed.nbytes),
                    "ms_per_frame_gpu_median": round(max(g[2] for g in per_rank), 4),
                    "ms_per_frame_gpu_mean": round(max(g[1] for g in per_rank) / args.steps, 4),
-                   "dispatch_floor_ms": round(max(g[3] for g in per_rank), 4),
+                   "dispatch_floor_ms": None if args.no_probes else round(max(g[3] for g in per_rank), 4),
                    "prewarm_launches": prewarm_launches},
     }
     if N > 1:
         result["config"]["per_rank"] = [{"rank": r, "wall_ms_per_step": round(g[0] / args.steps * 1e3, 4),
-                                         "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": round(g[3], 4)}
+                                         "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": None if args.no_probes else round(g[3], 4)}
                                         for r, g in enumerate(per_rank)]
 
     # ---- roofline (N = 1) -------------------------------------------------------------------------------------------

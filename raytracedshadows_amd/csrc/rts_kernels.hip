@@ -549,7 +549,7 @@ __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream&
 __device__ __forceinline__ bool blockToXY(const TraceParams& p, uint32_t bid, uint32_t* bx, uint32_t* by) {
     if (p.grid2d) {                              // natural order, launched as a blocksX x blocksY grid: no division
         *bx = blockIdx.x;
-        *by = blockIdx.y;
+        *by = p.bottomUp ? p.blocksY - 1u - blockIdx.y : blockIdx.y;
         return true;
     }
     uint32_t b = bid;
@@ -636,7 +636,9 @@ void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    // (PLAIN: a 2-D grid in raster order; with bottomUp the last tile row is dispatched first, so that the rows that
+    //  are launched last -- the tail of the kernel -- are the top of the image: sky, ceilings, the cheapest rays)
+    uint32_t bx = blockIdx.x, by = p.bottomUp ? p.blocksY - 1u - blockIdx.y : blockIdx.y;
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);

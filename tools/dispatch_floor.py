@@ -8,7 +8,7 @@ from raytracedshadows_amd import api, workloads
 
 def main():
 
-    wl = workloads.prepare_config("city_4k")
+    wl = workloads.prepare_config("city_4k", cache=True)
     W, H = wl.W, wl.H
     tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
     one = api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes
@@ -17,12 +17,12 @@ def main():
         ctx.h2d(d_pos, wl.positions)
         for name, packed in (("one-triangle BVH", one), ("city BVH", wl.packed)):
             ctx.set_bvh(packed)
-            for kern in (0, 3, 4, 5):
+            for kern in (0, 3, 4, 5, 8):
                 for bw in (1, 4):
                     if kern == 0 and bw == 1:
                         continue
                     ctx.set_option("kernel", kern); ctx.set_option("block_waves", bw); ctx.set_option("packet_budget", 1000)
-                    for _ in range(3):
+                    for _ in range(300):                  # clocks ramped before anything is timed
                         ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
                     ts = []
                     for _ in range(20):

@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline $*"
+ARGS="--no-cpu-baseline --no-pmc --no-probes $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 200 --warmup 20 $ARGS > $OUT/trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 i=0
@@ -16,12 +16,12 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_CVT" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_REQ_READ_8 SQC_TC_DATA_READ_REQ" "SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU" ; do
   i=$((i+1))
-  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $REPO/bench.py --steps 5 --warmup 2 $ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $REPO/bench.py --steps 5 --warmup 2 --prewarm-seconds 0 $ARGS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
   echo "pmc$i ($PMC) rc=$?"
 done
 # calibration of FETCH_SIZE / WRITE_SIZE: same dispatch, 1-triangle BVH => reads = the 132.7 MB position stream
 for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $PMC --output-format csv -d $OUT/calib_$PMC -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --config calib_4k > $OUT/calib_$PMC.json 2> $OUT/calib_$PMC.err
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/calib_$PMC -- python3 $REPO/bench.py --steps 5 --warmup 2 --prewarm-seconds 0 --no-cpu-baseline --no-pmc --config calib_4k > $OUT/calib_$PMC.json 2> $OUT/calib_$PMC.err
   echo "calib $PMC rc=$?"
 done
 cd $REPO
