@@ -36,7 +36,7 @@ struct rts_ctx {
     uint64_t launches = 0;
     uint32_t* d_tileQueue = nullptr;   // V_PERSIST: 64 shard heads + exit counter on their own 64-byte lines, zero between launches
     int queueRun = 4;
-    int bottomUp = 0;                  // dispatch tile rows last-to-first (2-D grids only)
+    int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
     int residentWaves = 0;             // 32 x compute units of the device
 };
 
@@ -204,7 +204,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     // (1..4096: the dissolve rule multiplies budget * share * live rays in 32 bits)
     if (!strcmp(key, "packet_budget")) { if (value < 1 || value > 4096) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
-    if (!strcmp(key, "bottom_up")) { c->bottomUp = value ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "row_order")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->rowOrder = value; return RTS_OK; }
     if (!strcmp(key, "queue_run")) { if (value < 1 || value > 64) return RTS_ERR_INVALID_ARG; c->queueRun = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
@@ -230,7 +230,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
     if (!strcmp(key, "queue_run")) { *value = c->queueRun; return RTS_OK; }
-    if (!strcmp(key, "bottom_up")) { *value = c->bottomUp; return RTS_OK; }
+    if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
@@ -293,7 +293,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (variant != rts::V_PERSIST && !p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
-    p.bottomUp = (p.grid2d && c->bottomUp && n_stripes <= 1) ? 1u : 0u;
+    p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;

@@ -32,7 +32,7 @@ struct TraceParams {
     uint32_t bandRows, nStripes, stripe;   // interleaved stripes (nStripes <= 1: plain rowBegin..rowEnd)
     uint32_t blocksX, blocksY, nBlocks, gridBlocks, swizzle;
     uint32_t grid2d;            // 1: launched as a blocksX x blocksY grid in natural order (no swizzle, no order table)
-    uint32_t bottomUp;          // 1: tile rows are dispatched from the last row to the first (speed only)
+    uint32_t rowOrder;          // dispatch order of the tile rows (speed only): 0 first to last, 1 last to first, 2 middle row outwards
     float cam[3];
     uint32_t lightType, nsamples;
     float light[3];

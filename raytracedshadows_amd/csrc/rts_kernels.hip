@@ -540,6 +540,20 @@ __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream&
     return traverseStraight<FAST>(bvh, r, live);
 }
 
+// Tile row worked on by the k-th row of workgroups of a 2-D launch.  The hardware starts workgroups in grid order, so
+// this is the order in which the rows of the image are begun -- and the rows begun last are the tail of the kernel, when
+// the machine runs empty.  Order 2 (middle row first, then alternately below and above it) makes that tail the top and
+// the bottom of the image: sky or ceiling, and the floor next to the camera -- on every scene measured the cheapest
+// rows, while the rows that hold the long waves (tools/floor_analysis.py) start early.  A bijection on [0, blocksY):
+// even k -> mid + k/2, odd k -> mid - (k+1)/2 with mid = blocksY/2.
+__device__ __forceinline__ uint32_t dispatchRow(const TraceParams& p, uint32_t k) {
+    if (p.rowOrder == 2u) {
+        const uint32_t mid = p.blocksY >> 1;
+        return (k & 1u) ? mid - ((k + 1u) >> 1) : mid + (k >> 1);
+    }
+    return p.rowOrder == 1u ? p.blocksY - 1u - k : k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile mapping: wave -> 8x8 pixel tile.  A 256-thread block is a 2x2 group of tiles (16x16 px).
 // With swizzle on, blocks that share an XCD (blockIdx % 8, round-robin dispatch) get a contiguous
@@ -549,7 +563,7 @@ __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream&
 __device__ __forceinline__ bool blockToXY(const TraceParams& p, uint32_t bid, uint32_t* bx, uint32_t* by) {
     if (p.grid2d) {                              // natural order, launched as a blocksX x blocksY grid: no division
         *bx = blockIdx.x;
-        *by = p.bottomUp ? p.blocksY - 1u - blockIdx.y : blockIdx.y;
+        *by = dispatchRow(p, blockIdx.y);
         return true;
     }
     uint32_t b = bid;
@@ -636,9 +650,7 @@ void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
-    // (PLAIN: a 2-D grid in raster order; with bottomUp the last tile row is dispatched first, so that the rows that
-    //  are launched last -- the tail of the kernel -- are the top of the image: sky, ceilings, the cheapest rays)
-    uint32_t bx = blockIdx.x, by = p.bottomUp ? p.blocksY - 1u - blockIdx.y : blockIdx.y;
+    uint32_t bx = blockIdx.x, by = dispatchRow(p, blockIdx.y);       // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);
