@@ -133,6 +133,9 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *   "packet_share"  a packet dissolves when it picks up fewer than share/16 of its live rays per side-step (default 4)
  *   "block_waves"   waves per workgroup of the packet kernels: 1 (default) or 4
  *   "xcd_swizzle"   1 = contiguous image chunk per XCD (default 0: measured slower)
+ *   "row_order"     order in which the tile rows of a frame are dispatched: 0 first to last (default), 1 last to first,
+ *                   2 middle row outwards (the rows dispatched last are the kernel's tail; which order wins depends on
+ *                   where the scene's long rays are: profiles/r02/row_order_sweep.log)
  *   "lds_pad"       experiment: extra dynamic LDS bytes per one-wave packet workgroup (throttles occupancy; default 0)
  *   "wave_stats"    diagnostics, see rts_ctx_read_wave_stats
  *   get only: "bvh_finite", "bvh_ordered" (which slab-test forms the uploaded stream allows) */

@@ -34,10 +34,7 @@ struct rts_ctx {
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
-    uint32_t* d_tileQueue = nullptr;   // V_PERSIST: 64 shard heads + exit counter on their own 64-byte lines, zero between launches
-    int queueRun = 4;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
-    int residentWaves = 0;             // 32 x compute units of the device
 };
 
 namespace {
@@ -143,12 +140,6 @@ int rts_ctx_create(int device, rts_ctx** out) {
     hipError_t e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) { delete c; return hipStatus(e); }
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, device);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_tileQueue, 65 * 64);
-    if (e == hipSuccess) e = hipMemset(c->d_tileQueue, 0, 65 * 64);
-    if (e != hipSuccess) { (void)rts_ctx_destroy(c); return hipStatus(e); }
-    c->residentWaves = prop.multiProcessorCount * 32;
     *out = c;
     return RTS_OK;
 }
@@ -161,7 +152,6 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_waveStats) (void)hipFree(c->d_waveStats);
     if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
-    if (c->d_tileQueue) (void)hipFree(c->d_tileQueue);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -205,7 +195,6 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "packet_budget")) { if (value < 1 || value > 4096) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
     if (!strcmp(key, "row_order")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->rowOrder = value; return RTS_OK; }
-    if (!strcmp(key, "queue_run")) { if (value < 1 || value > 64) return RTS_ERR_INVALID_ARG; c->queueRun = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
@@ -229,7 +218,6 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "block_waves")) { *value = c->blockWaves; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
-    if (!strcmp(key, "queue_run")) { *value = c->queueRun; return RTS_OK; }
     if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
@@ -264,35 +252,19 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     const uint64_t pixels = (uint64_t)W * rows;
     if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_SHARE;
-    // the persistent grid covers one contiguous row range in natural tile order; interleaved stripes, a caller-given
-    // tile order, the XCD swizzle and the diagnostics stay with the one-shot packet kernel (same walk, same bits)
-    if (variant == rts::V_PERSIST && (n_stripes > 1 || c->d_tileOrder || c->swizzle)) variant = rts::V_PACKET;
-    for (;;) {
-        uint32_t bw, bh;
-        rts::tileShape(variant, c->blockWaves, &bw, &bh);
-        p.blocksX = (W + bw - 1) / bw;
-        p.blocksY = (rows + bh - 1) / bh;
-        p.nBlocks = p.blocksX * p.blocksY;
-        p.swizzle = c->swizzle ? 1u : 0u;
-        p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
-        if (variant != rts::V_PERSIST) break;
-        // tile -> (x, y) on the device is floor(tile * magic / 2^32) with magic = ceil(2^32 / blocksX): exact while
-        // nBlocks * (magic * blocksX - 2^32) < 2^32 (always true for frames below ~2^16 tiles per row and column)
-        const uint64_t magic = (0x100000000ull + p.blocksX - 1) / p.blocksX;
-        const bool exact = magic <= 0xFFFFFFFFull && (uint64_t)p.nBlocks * (magic * p.blocksX - 0x100000000ull) < 0x100000000ull;
-        if (!exact || p.nBlocks > 0x0FFFFFFFu) { variant = rts::V_PACKET; continue; }
-        p.blocksXMagic = (uint32_t)magic;
-        p.tileQueue = c->d_tileQueue;
-        p.queueRun = (uint32_t)c->queueRun;
-        p.gridBlocks = p.nBlocks < (uint32_t)c->residentWaves ? p.nBlocks : (uint32_t)c->residentWaves;
-        break;
-    }
+    uint32_t bw, bh;
+    rts::tileShape(variant, c->blockWaves, &bw, &bh);
+    p.blocksX = (W + bw - 1) / bw;
+    p.blocksY = (rows + bh - 1) / bh;
+    p.nBlocks = p.blocksX * p.blocksY;
+    p.swizzle = c->swizzle ? 1u : 0u;
+    p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
     if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) {
         p.waveStats = c->d_waveStats;
         p.waveRealtime = c->d_waveStats + c->waveStatsBytes / 8;
     }
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
-    p.grid2d = (variant != rts::V_PERSIST && !p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
+    p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {

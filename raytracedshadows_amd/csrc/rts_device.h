@@ -14,7 +14,6 @@ enum Variant {
     V_PACKET4 = 5,     // same, 4 rays per lane (16x16 px per wave)
     V_PACKET_PF = 6,   // V_PACKET with the sequential successor node prefetched into a second SGPR set
     V_SHARE = 7,       // lane-per-ray with work sharing inside the wave (idle lanes take half of a busy ray's range)
-    V_PERSIST = 8,     // V_PACKET as a persistent grid: resident waves pull runs of tiles from per-XCD queues
     V_COUNT,
     V_AUTO = -1        // packet for big launches, V_SHARE for small ones and for generic rays
 };
@@ -43,9 +42,6 @@ struct TraceParams {
     const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
     uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
-    uint32_t* tileQueue;      // V_PERSIST: 64 shard heads (one per 64-B line) + exit counter, all zero between launches
-    uint32_t queueRun;        // (unused)
-    uint32_t blocksXMagic;    // V_PERSIST: ceil(2^32 / blocksX) for tile -> (x, y) without a division (tiles < 2^16 * ...)
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
     float offsets[64][4];

@@ -407,8 +407,8 @@ template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], uint32_t* lds,
                                                int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr) {
-    // (the stream's address as an explicitly wave-uniform value: inside the persistent kernel's tile loop the compiler
-    //  otherwise keeps the kernel argument in VGPRs, which the asm's scalar loads cannot take)
+    // (the stream's address as an explicitly wave-uniform value: when this function is inlined into a loop over tiles the
+    //  compiler may keep the kernel argument in VGPRs, which the asm's scalar loads cannot take)
     const uint64_t bvhAddr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)p.bvh >> 32)) << 32) |
                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p.bvh);
     const void* const bvhBase = (const void*)(uintptr_t)bvhAddr;
@@ -718,146 +718,6 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// V_PERSIST: the packet kernel (K = 1) as a persistent grid.
-//
-// Measured on the one-wave-workgroup launch (tools/floor_analysis.py): the dispatcher starts ~2 100 waves per
-// microsecond chip-wide, so a 4K frame's 129 600 tiles cost 58 us before any traversal, and in steady state a wave
-// slot stays empty for ~1.7-3 us between the end of one wave and the first instruction of its successor (6 700-6 900
-// of 8 192 slots busy on the headline frame).  Here exactly one wave per slot is launched and stays: it pulls tiles
-// from a queue, requests the G-buffer texel of its next tile before it walks the current one, and leaves when every
-// queue is empty.
-//
-// Queues: tiles are dealt round-robin into 64 shards (tile i -> shard i % 64; shard % 8 is what the hardware's
-// round-robin workgroup placement gives the one-shot kernel as XCD, so each XCD's L2 sees the same tiles).  A shard's
-// head is one word on its own 64-byte line; a tile is taken with one returning device-scope atomic add, issued one tile
-// ahead so that its latency (and that of the texel load it leads to) lies under the walk of the current tile.  64 heads
-// keep each below ~15 takes per microsecond (one word saturates near 88).  A wave starts on a shard of its own XCD
-// (HW_REG_XCC_ID) and, when that is empty, looks at all 64 heads with one vector load and moves to a non-empty one, so
-// nothing depends on the placement, on the number of XCDs of the partition, or on how many waves are resident: every
-// wave that runs takes work until none is left, and no wave ever waits for another.  The last wave to leave (exit
-// counter) zeroes the heads for the next launch.
-// ------------------------------------------------------------------------------------------------
-static constexpr uint32_t QUEUE_SHARDS = 64;
-static constexpr uint32_t QUEUE_STRIDE = 16;     // words between shard heads: one 64-byte line each
-
-__device__ __forceinline__ uint32_t shardTiles(uint32_t nTiles, uint32_t shard) { return (nTiles + (QUEUE_SHARDS - 1u) - shard) / QUEUE_SHARDS; }
-
-__device__ __forceinline__ uint32_t takeTile(uint32_t* queue, uint32_t shard, uint32_t lane) {   // per-lane result valid in lane 0
-    uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(queue + shard * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-}
-
-template <bool SOFT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
-void shadowMaskPersistentKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[1][64];
-    uint32_t* lds = shareSlots[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    const NodeStream bvh = openStream(p);
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    uint32_t shard = (xcc & 7u) + 8u * ((blockIdx.x >> 3) & 7u);
-    uint32_t count = shardTiles(p.nBlocks, shard);
-    const uint64_t tStart = p.waveStats ? __builtin_amdgcn_s_memtime() : 0;          // diagnostics only
-    const uint64_t rStart = p.waveStats ? __builtin_amdgcn_s_memrealtime() : 0;
-    uint32_t tilesDone = 0, moves = 0;
-    // first tile: taken and loaded in the open
-    uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)takeTile(p.tileQueue, shard, lane));
-    bool loaded = false;                       // `rel` holds the texel of tile j of `shard`
-    F3 rel{ 0.f, 0.f, 0.f };
-    uint32_t pending = 0;                      // lane 0: the take issued one tile ahead
-    bool havePending = false;
-    for (;;) {
-        shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)shard);
-        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
-        if (j >= count) {
-            // this shard is empty: one look at all heads, move to a shard that still has tiles (own XCD's first)
-            const uint32_t head = __hip_atomic_load(p.tileQueue + lane * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t open = __builtin_amdgcn_ballot_w64(head < shardTiles(p.nBlocks, lane));
-            if (open == 0) break;
-            const uint64_t mine = open & (0x0101010101010101ull << (xcc & 7u));
-            if (mine) open = mine;
-            // spread the movers: start the search at a position derived from this wave's number
-            const uint32_t rot = (blockIdx.x * 7u) & 63u;
-            const uint64_t rotated = (open >> rot) | (rot ? open << (64u - rot) : 0ull);
-            shard = ((uint32_t)__builtin_ctzll(rotated) + rot) & 63u;
-            count = shardTiles(p.nBlocks, shard);
-            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)takeTile(p.tileQueue, shard, lane));
-            loaded = false;
-            havePending = false;
-            ++moves;
-            continue;
-        }
-        // tile -> (bx, by): tile / blocksX through the precomputed reciprocal (exactness checked on the host)
-        const uint32_t tile = shard + QUEUE_SHARDS * j;
-        const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(((uint64_t)tile * p.blocksXMagic) >> 32));
-        const uint32_t bx = tile - by * p.blocksX;
-        const uint32_t x = bx * 8u + (lane & 7u);
-        const uint32_t y = p.rowBegin + by * 8u + (lane >> 3);
-        const bool live = (x < p.W) && (y < p.rowEnd);
-        const size_t pix = (size_t)y * p.W + x;
-        if (!loaded) {
-            rel = F3{ 0.f, 0.f, 0.f };
-            if (live) {
-                f32x4 t4 = __builtin_nontemporal_load((const f32x4*)p.positions + pix);       // comp:135
-                rel = F3{ t4.x, t4.y, t4.z };
-            }
-        }
-        // the tile after this one: its index was requested one tile ago; request its texel and the index after it now,
-        // both travel while this tile is walked
-        uint32_t jNext = count;
-        if (havePending) jNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
-        else jNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)takeTile(p.tileQueue, shard, lane));
-        F3 relNext{ 0.f, 0.f, 0.f };
-        const bool haveNext = jNext < count;
-        if (haveNext) {
-            const uint32_t tile2 = shard + QUEUE_SHARDS * jNext;
-            const uint32_t by2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(((uint64_t)tile2 * p.blocksXMagic) >> 32));
-            const uint32_t bx2 = tile2 - by2 * p.blocksX;
-            const uint32_t x2 = bx2 * 8u + (lane & 7u), y2 = p.rowBegin + by2 * 8u + (lane >> 3);
-            if ((x2 < p.W) && (y2 < p.rowEnd)) {
-                f32x4 t4 = __builtin_nontemporal_load((const f32x4*)p.positions + ((size_t)y2 * p.W + x2));
-                relNext = F3{ t4.x, t4.y, t4.z };
-            }
-            pending = takeTile(p.tileQueue, shard, lane);
-        }
-        havePending = haveNext;
-        const uint32_t ns = SOFT ? p.nsamples : 1u;
-        uint32_t lit = 0;
-        for (uint32_t s = 0; s < ns; ++s) {
-            const Ray r[1] = { makeShadowRay(p, rel, s) };
-            const bool ll[1] = { live };
-            bool occluded[1];
-            traversePacket<1, false>(p, bvh, r, ll, occluded, lds);
-            lit += occluded[0] ? 0u : 1u;                                                     // comp:148
-        }
-        if (live) __builtin_nontemporal_store((uint8_t)lit, &p.mask[pix]);                    // comp:150
-        j = jNext;
-        rel = relNext;
-        loaded = haveNext;
-        ++tilesDone;
-    }
-    if (p.waveStats && lane == 0) {              // diagnostics: never read by any kernel, never part of an output
-        uint64_t* o = p.waveStats + (size_t)blockIdx.x * 4;
-        o[0] = tStart; o[1] = __builtin_amdgcn_s_memtime(); o[2] = tilesDone; o[3] = ((uint64_t)xcc << 32) | moves;
-        p.waveRealtime[(size_t)blockIdx.x * 4] = rStart;
-        p.waveRealtime[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        p.waveRealtime[(size_t)blockIdx.x * 4 + 2] = 0;
-        p.waveRealtime[(size_t)blockIdx.x * 4 + 3] = xcc;
-    }
-    // the last wave out leaves the queue as it found it: all zero
-    uint32_t done = 0;
-    if (lane == 0) done = __hip_atomic_fetch_add(p.tileQueue + QUEUE_SHARDS * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
-    if (done == gridDim.x - 1u) {
-        __hip_atomic_store(p.tileQueue + lane * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) __hip_atomic_store(p.tileQueue + QUEUE_SHARDS * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 template <int VARIANT>
 __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[4][64];
@@ -903,14 +763,13 @@ const char* kernelName(int variant, bool mask) {
     case V_PACKET4: return mask ? "shadowMaskPacketKernel<4>" : "traceRaysKernel<3>";
     case V_PACKET_PF: return mask ? "shadowMaskPacketKernel<1,pf>" : "traceRaysKernel<3>";
     case V_SHARE: return mask ? "shadowMaskKernel<7>" : "traceRaysKernel<7>";
-    case V_PERSIST: return mask ? "shadowMaskPersistentKernel" : "traceRaysKernel<3>";
     }
     return "?";
 }
 
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH) {
-    const bool packet = (variant >= V_PACKET && variant <= V_PACKET_PF) || variant == V_PERSIST;
-    const uint32_t f = ((packet && wavesPerBlock == 1) || variant == V_PERSIST) ? 1u : 2u;   // block = f x f wave tiles
+    const bool packet = variant >= V_PACKET && variant <= V_PACKET_PF;
+    const uint32_t f = (packet && wavesPerBlock == 1) ? 1u : 2u;                // block = f x f wave tiles
     *blockW = f * ((variant == V_PACKET2 || variant == V_PACKET4) ? 16u : 8u);
     *blockH = f * (variant == V_PACKET4 ? 16u : 8u);
 }
@@ -919,11 +778,6 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     dim3 grid(p.gridBlocks), block(256);
     if (p.grid2d) grid = dim3(p.blocksX, p.blocksY);
     const bool soft = p.nsamples > 1;
-    if (variant == V_PERSIST) {                    // gridBlocks = resident waves (set by the caller), one wave per workgroup
-        if (soft) hipLaunchKernelGGL(shadowMaskPersistentKernel<true>, dim3(p.gridBlocks), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL(shadowMaskPersistentKernel<false>, dim3(p.gridBlocks), dim3(64), 0, stream, p);
-        return hipGetLastError();
-    }
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
@@ -961,7 +815,7 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
     case V_WHILEWHILE: hipLaunchKernelGGL(traceRaysKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(traceRaysKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
     case V_SHARE: hipLaunchKernelGGL(traceRaysKernel<V_SHARE>, grid, block, 0, stream, p); break;
-    case V_PACKET: case V_PACKET2: case V_PACKET4: case V_PACKET_PF: case V_PERSIST:
+    case V_PACKET: case V_PACKET2: case V_PACKET4: case V_PACKET_PF:
         hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }

@@ -410,8 +410,14 @@ def test_tuning_options_never_change_the_mask(ctx):
     want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
                                     oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
     ctx.set_bvh(wl.packed)
-    defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel")}
+    defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel", "row_order")}
     try:
+        for kernel in (-1, 0, 3, 5, 7):                      # dispatch order of the tile rows: 2-D grids of every kernel family
+            for order in (1, 2, 0):
+                ctx.set_option("kernel", kernel)
+                ctx.set_option("row_order", order)
+                got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
+                assert (got == want).all(), (kernel, "row_order", order)
         for kernel in (-1, 3, 4, 5):
             for budget, share in ((1, 16), (1, 0), (2, 8), (8, 4), (64, 16), (64, 1)):
                 for bw in (1, 4):
