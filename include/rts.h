@@ -103,14 +103,21 @@ int rts_bvh_build_ex(const float* vertices, uint32_t stride_floats, const uint32
  * count == 5P-2, leaf/inner tags, strictly-forward miss links, tail pointers in range. */
 int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_count_out);
 
-/* BVH build ON THE GPU: Morton order + Karras hierarchy + bottom-up bounds, then the reference's
+/* BVH build ON THE GPU: a topology over the Morton order of the triangles, then the reference's
  * layout rules (larger-area child first, DFS numbering, miss links, tail; BVHBuilder.cpp:202-244, 308-367).  The tree is
  * NOT BVHBuilder's SAH tree (use rts_bvh_build for that); it is another valid producer of the same packed layout.
+ * rts_bvh_build_device = PLOC with radius 16 (the better tree); rts_bvh_build_device_ex picks the topology:
+ *   RTS_GPU_BUILD_LBVH  Karras hierarchy + bottom-up bounds (fastest build)
+ *   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering, `radius` = Morton neighbours searched each way (0 = 16)
  * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
  * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build. */
+enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1 };
 int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
                          const uint32_t* indices, uint32_t prim_count, rts_vec4u* out_packed,
                          size_t out_capacity_vec4, int install, float* build_ms);
+int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
+                            const uint32_t* indices, uint32_t prim_count, int algorithm, uint32_t radius,
+                            rts_vec4u* out_packed, size_t out_capacity_vec4, int install, float* build_ms);
 
 /* ---- consumer: replaces the bind-group + dispatch of
  *      RayTracedShadowsApp::renderShadowMaskCompute (Source/RayTracedShadows.cpp:570-595) and the

@@ -114,6 +114,8 @@ _sig("rts_bvh_build_ex", C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32
 _sig("rts_bvh_validate", C.c_int, C.c_void_p, C.c_size_t, _u32p)
 _sig("rts_bvh_build_device", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32,
      C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float))
+_sig("rts_bvh_build_device_ex", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+     C.c_uint32, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float))
 _sig("rts_device_count", C.c_int, C.POINTER(C.c_int))
 _sig("rts_ctx_create", C.c_int, C.c_int, C.POINTER(C.c_void_p))
 _sig("rts_ctx_destroy", C.c_int, C.c_void_p)
@@ -217,16 +219,19 @@ class BVHBuilder:
         return self
 
 
-def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, want_packed=True):
-    """BVH build on the GPU (LBVH).  Returns (packed or None, device milliseconds)."""
+def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, want_packed=True, algorithm="ploc",
+                     radius=16):
+    """BVH build on the GPU ("ploc": locally-ordered clustering, default; "lbvh": Karras hierarchy).
+    Returns (packed or None, device milliseconds)."""
     vertices = np.ascontiguousarray(vertices, dtype=np.float32)
     indices = np.ascontiguousarray(indices, dtype=np.uint32)
     n = packed_count(prim_count)
     packed = np.zeros((max(n, 1), 4), dtype=np.uint32) if want_packed else None
     ms = C.c_float(0)
-    _check(_lib.rts_bvh_build_device(ctx.handle, _ptr(vertices), vertices.size, stride, _ptr(indices), prim_count,
-                                     _ptr(packed) if want_packed else None, n if want_packed else 0, int(install),
-                                     C.byref(ms)), "rts_bvh_build_device")
+    algo = {"lbvh": 0, "ploc": 1}[algorithm]
+    _check(_lib.rts_bvh_build_device_ex(ctx.handle, _ptr(vertices), vertices.size, stride, _ptr(indices), prim_count,
+                                        algo, radius, _ptr(packed) if want_packed else None, n if want_packed else 0,
+                                        int(install), C.byref(ms)), "rts_bvh_build_device_ex")
     return (packed[:n] if want_packed else None), float(ms.value)
 
 

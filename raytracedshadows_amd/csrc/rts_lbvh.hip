@@ -1,6 +1,10 @@
 // BVH build on the GPU: an alternative PRODUCER of the packed node stream of SURVEY.md
-// Appendix A.  Linear BVH: Morton order of the triangle centroids (63-bit codes, hipcub radix sort), Karras'
-// parallel hierarchy, bottom-up bounds, then the reference's own layout rules applied to that topology:
+// Appendix A.  Two topologies over the Morton order of the triangle centroids (63-bit codes, hipcub radix sort):
+//   RTS_GPU_BUILD_LBVH  Karras' parallel hierarchy (one kernel) + bottom-up bounds: fastest build, weakest tree
+//   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering (Meister & Bittner 2018): every cluster looks `radius`
+//                       neighbours up and down the Morton order for the partner whose union has the smallest surface
+//                       area, mutual pairs merge, the array is compacted, repeat until one cluster is left (default)
+// then the reference's own layout rules applied to that topology:
 //   * child with the larger surface area first            (Source/BVHBuilder.cpp:202-208, strict `>` on the right one)
 //   * depth-first (pre-order) numbering, left child = i+1 (cpp:222-238)
 //   * miss link = first index after the subtree, 0xFFFFFFFF at the end (cpp:231-236)
@@ -14,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <utility>
 #include "../../include/rts.h"
 
 extern "C" int rts_ctx_adopt_device_bvh(rts_ctx* ctx, void* d_packed, size_t count_vec4, uint32_t prim_count);  // rts_api.cpp
@@ -174,6 +179,97 @@ __global__ void refitCommitKernel(Lbvh b) {
     if (i < b.P - 1 && b.done[i] == 2) b.done[i] = 1;
 }
 
+// ---- PLOC ------------------------------------------------------------------------------------------------------
+// Cluster arrays (position in the current Morton-ordered list -> node id and box).  Node ids as everywhere in this
+// file: internal 0..P-2, leaf at sorted position j = P-1+j.
+struct Ploc {
+    uint32_t n;                            // clusters in the list
+    uint32_t radius;
+    uint32_t* id; float* lo; float* hi;    // current list (3 floats per box)
+    uint32_t* idOut; float* loOut; float* hiOut;   // compacted list of the next round
+    uint32_t* nn;                          // nearest neighbour (position) of every cluster
+    uint32_t* valid;                       // 1: the cluster at this position survives the round
+    uint32_t* pos;                         // exclusive scan of valid
+    uint32_t* nextId;                      // [0] = next free internal node id
+};
+
+__global__ void plocInitKernel(Lbvh b, Ploc c, const uint32_t* order) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.P) return;
+    const uint32_t prim = order[j];
+    c.id[j] = b.P - 1 + j;
+    for (int a = 0; a < 3; ++a) { c.lo[(size_t)j * 3 + a] = b.leafLo[(size_t)prim * 3 + a]; c.hi[(size_t)j * 3 + a] = b.leafHi[(size_t)prim * 3 + a]; }
+}
+
+// Nearest neighbour within `radius` positions: smallest surface area of the union, ties to the lower position.  (The
+// pair with the globally smallest distance, lowest positions first, is always mutual: every round merges something.)
+__global__ void plocNearestKernel(Ploc c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = c.lo[(size_t)i * 3 + a]; hi[a] = c.hi[(size_t)i * 3 + a]; }
+    const uint32_t first = i > c.radius ? i - c.radius : 0u;
+    const uint32_t last = i + c.radius < c.n ? i + c.radius : c.n - 1u;
+    float best = __builtin_inff();
+    uint32_t bestJ = END;
+    for (uint32_t j = first; j <= last; ++j) {
+        if (j == i) continue;
+        float ulo[3], uhi[3];
+        for (int a = 0; a < 3; ++a) {
+            const float l = c.lo[(size_t)j * 3 + a], h = c.hi[(size_t)j * 3 + a];
+            ulo[a] = l < lo[a] ? l : lo[a];
+            uhi[a] = h > hi[a] ? h : hi[a];
+        }
+        const float d = surfaceArea(ulo, uhi);
+        if (d < best || bestJ == END) { best = d; bestJ = j; }            // (also takes the first candidate when every area is inf/NaN)
+    }
+    c.nn[i] = bestJ;
+}
+
+// Mutual pairs merge into a new internal node at the lower position; the higher position is dropped.
+__global__ void plocMergeKernel(Lbvh b, Ploc c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    const uint32_t j = c.nn[i];
+    const bool mutual = j != END && c.nn[j] == i;
+    if (!mutual) { c.valid[i] = 1; return; }
+    if (i > j) { c.valid[i] = 0; return; }
+    c.valid[i] = 1;
+    const uint32_t node = atomicAdd(&c.nextId[0], 1u);
+    uint32_t kid[2] = { c.id[i], c.id[j] };
+    float lo[2][3], hi[2][3];
+    for (int a = 0; a < 3; ++a) {
+        lo[0][a] = c.lo[(size_t)i * 3 + a]; hi[0][a] = c.hi[(size_t)i * 3 + a];
+        lo[1][a] = c.lo[(size_t)j * 3 + a]; hi[1][a] = c.hi[(size_t)j * 3 + a];
+    }
+    const bool swap = surfaceArea(lo[1], hi[1]) > surfaceArea(lo[0], hi[0]);    // larger child first (cpp:202-208)
+    b.child[2 * node] = kid[swap ? 1 : 0];
+    b.child[2 * node + 1] = kid[swap ? 0 : 1];
+    b.parent[kid[0]] = node;
+    b.parent[kid[1]] = node;
+    uint32_t leaves = 0;
+    for (int k = 0; k < 2; ++k) leaves += kid[k] >= b.P - 1 ? 1u : b.leaves[kid[k]];
+    b.leaves[node] = leaves;
+    for (int a = 0; a < 3; ++a) {
+        const float l = lo[0][a] < lo[1][a] ? lo[0][a] : lo[1][a], h = hi[0][a] > hi[1][a] ? hi[0][a] : hi[1][a];
+        b.nodeLo[(size_t)node * 3 + a] = l; b.nodeHi[(size_t)node * 3 + a] = h;
+        c.lo[(size_t)i * 3 + a] = l; c.hi[(size_t)i * 3 + a] = h;          // position i now holds the merged cluster
+    }
+    c.id[i] = node;
+}
+
+__global__ void plocCompactKernel(Ploc c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n || !c.valid[i]) return;
+    const uint32_t o = c.pos[i];
+    c.idOut[o] = c.id[i];
+    for (int a = 0; a < 3; ++a) { c.loOut[(size_t)o * 3 + a] = c.lo[(size_t)i * 3 + a]; c.hiOut[(size_t)o * 3 + a] = c.hi[(size_t)i * 3 + a]; }
+}
+
+__global__ void plocRootKernel(Lbvh b, Ploc c) {                       // the last cluster is the root
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.parent[c.id[0]] = END;
+}
+
 // Pre-order index of a node = sum over its ancestors of (1 + size of the sibling subtree visited before it).
 __global__ void emitKernel(Lbvh b, const uint32_t* order, uint32_t* packed) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,7 +320,7 @@ __global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P 
 }
 
 struct DeviceArena {            // frees everything it handed out, whatever path leaves the function
-    void* ptrs[24]; int n = 0;
+    void* ptrs[40]; int n = 0;
     hipEvent_t ev[2] = { nullptr, nullptr };
     template <typename T> hipError_t get(T** p, size_t bytes) {
         void* v = nullptr;
@@ -243,10 +339,12 @@ struct DeviceArena {            // frees everything it handed out, whatever path
 
 } // namespace
 
-extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
-                                    const uint32_t* indices, uint32_t P, rts_vec4u* out_packed, size_t out_cap,
-                                    int install, float* build_ms) {
+extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
+                                       const uint32_t* indices, uint32_t P, int algorithm, uint32_t radius,
+                                       rts_vec4u* out_packed, size_t out_cap, int install, float* build_ms) {
     if (!ctx || !vertices || !indices || P == 0 || stride < 3 || P > 0x0CCCCCCCu) return RTS_ERR_INVALID_ARG;
+    if ((algorithm != RTS_GPU_BUILD_LBVH && algorithm != RTS_GPU_BUILD_PLOC) || radius > 256) return RTS_ERR_INVALID_ARG;
+    if (radius == 0) radius = 16;
     const size_t count = (size_t)5 * P - 2;
     if (out_packed && out_cap < count) return RTS_ERR_CAPACITY;
     for (size_t i = 0; i < (size_t)3 * P; ++i)
@@ -300,16 +398,48 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
         LB_HIP(arena.get(&temp, tempBytes));
         LB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, b.keys, keysAlt, b.order, orderAlt, (int)P, 0, 63, nullptr));
         sortedKeys = keysAlt; sortedOrder = orderAlt;
-        hipLaunchKernelGGL(hierarchyKernel, gridP, block, 0, nullptr, b, sortedKeys);
-        // bottom-up bounds: repeated sweeps, each finalising the nodes whose children were final before it
-        uint32_t left = pend;
-        for (int sweep = 0; sweep < 4096 && left != 0; ++sweep) {
-            hipLaunchKernelGGL(refitSweepKernel, gridP, block, 0, nullptr, b, sortedOrder);
-            hipLaunchKernelGGL(refitCommitKernel, gridP, block, 0, nullptr, b);
-            if ((sweep & 7) == 7 || sweep < 2) LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
+        if (algorithm == RTS_GPU_BUILD_PLOC) {
+            Ploc c{};
+            c.n = P; c.radius = radius;
+            LB_HIP(arena.get(&c.id, (size_t)P * 4)); LB_HIP(arena.get(&c.idOut, (size_t)P * 4));
+            LB_HIP(arena.get(&c.lo, (size_t)P * 12)); LB_HIP(arena.get(&c.hi, (size_t)P * 12));
+            LB_HIP(arena.get(&c.loOut, (size_t)P * 12)); LB_HIP(arena.get(&c.hiOut, (size_t)P * 12));
+            LB_HIP(arena.get(&c.nn, (size_t)P * 4)); LB_HIP(arena.get(&c.valid, (size_t)P * 4)); LB_HIP(arena.get(&c.pos, (size_t)P * 4));
+            LB_HIP(arena.get(&c.nextId, 16));
+            LB_HIP(hipMemset(c.nextId, 0, 16));
+            size_t scanBytes = 0;
+            LB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, c.valid, c.pos, (int)P, nullptr));
+            void* scanTemp;
+            LB_HIP(arena.get(&scanTemp, scanBytes));
+            hipLaunchKernelGGL(plocInitKernel, gridP, block, 0, nullptr, b, c, sortedOrder);
+            for (uint32_t round = 0; c.n > 1; ++round) {
+                if (round > 4u * 1024u * 1024u) { arena.release(); return RTS_ERR_BAD_BVH; }      // (every round merges at least one pair)
+                const dim3 grid((c.n + 255) / 256);
+                hipLaunchKernelGGL(plocNearestKernel, grid, block, 0, nullptr, c);
+                hipLaunchKernelGGL(plocMergeKernel, grid, block, 0, nullptr, b, c);
+                LB_HIP(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, c.valid, c.pos, (int)c.n, nullptr));
+                hipLaunchKernelGGL(plocCompactKernel, grid, block, 0, nullptr, c);
+                uint32_t tail[2] = { 0, 0 };
+                LB_HIP(hipMemcpy(&tail[0], c.pos + (c.n - 1), 4, hipMemcpyDeviceToHost));
+                LB_HIP(hipMemcpy(&tail[1], c.valid + (c.n - 1), 4, hipMemcpyDeviceToHost));
+                const uint32_t next = tail[0] + tail[1];
+                if (next == 0 || next >= c.n) { arena.release(); return RTS_ERR_BAD_BVH; }
+                c.n = next;
+                std::swap(c.id, c.idOut); std::swap(c.lo, c.loOut); std::swap(c.hi, c.hiOut);
+            }
+            hipLaunchKernelGGL(plocRootKernel, dim3(1), dim3(64), 0, nullptr, b, c);
+        } else {
+            hipLaunchKernelGGL(hierarchyKernel, gridP, block, 0, nullptr, b, sortedKeys);
+            // bottom-up bounds: repeated sweeps, each finalising the nodes whose children were final before it
+            uint32_t left = pend;
+            for (int sweep = 0; sweep < 4096 && left != 0; ++sweep) {
+                hipLaunchKernelGGL(refitSweepKernel, gridP, block, 0, nullptr, b, sortedOrder);
+                hipLaunchKernelGGL(refitCommitKernel, gridP, block, 0, nullptr, b);
+                if ((sweep & 7) == 7 || sweep < 2) LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
+            }
+            LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
+            if (left != 0) { arena.release(); return RTS_ERR_BAD_BVH; }
         }
-        LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
-        if (left != 0) { arena.release(); return RTS_ERR_BAD_BVH; }
         hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, sortedOrder, (uint32_t*)d_packed);
     } else {
         hipLaunchKernelGGL(emitSingleKernel, dim3(1), dim3(64), 0, nullptr, b, (uint32_t*)d_packed);
@@ -328,4 +458,11 @@ extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t 
     }
     arena.release();
     return RTS_OK;
+}
+
+extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
+                                    const uint32_t* indices, uint32_t P, rts_vec4u* out_packed, size_t out_cap,
+                                    int install, float* build_ms) {
+    return rts_bvh_build_device_ex(ctx, vertices, vertex_floats, stride, indices, P, RTS_GPU_BUILD_PLOC, 16, out_packed,
+                                   out_cap, install, build_ms);
 }

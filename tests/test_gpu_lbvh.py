@@ -1,4 +1,4 @@
-"""GPU: the BVH producer on the GPU (rts_bvh_build_device).  Its tree is not BVHBuilder's SAH tree,
+"""GPU: the BVH producers on the GPU (rts_bvh_build_device[_ex]: PLOC and LBVH).  Their trees are not BVHBuilder's SAH tree,
 so the checks are: the stream obeys every layout rule of Appendix A (same invariants the oracle's builder is held to),
 the kernels traced against it equal the CPU oracle traced against THE SAME stream bit for bit, and the resulting mask
 agrees with the SAH stream's mask up to the slab test's non-conservativeness."""
@@ -25,10 +25,14 @@ def _soup(n, seed):
     return (c + (rs.random_sample((n, 3, 3)) - 0.5) * 1.5).astype(np.float32).reshape(-1, 3), np.arange(3 * n, dtype=np.uint32)
 
 
+ALGOS = ["ploc", "lbvh"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("n,seed", [(1, 0), (2, 1), (3, 2), (17, 3), (1000, 4), (30011, 5)])
-def test_stream_obeys_the_layout_rules(ctx, n, seed):
+def test_stream_obeys_the_layout_rules(ctx, n, seed, algo):
     v, idx = _soup(n, seed)
-    packed, ms = api.bvh_build_device(ctx, v, 3, idx, n)
+    packed, ms = api.bvh_build_device(ctx, v, 3, idx, n, algorithm=algo)
     assert api.bvh_validate(packed) == n
     if n <= 1000:
         _invariants(packed, n)
@@ -42,24 +46,40 @@ def test_stream_obeys_the_layout_rules(ctx, n, seed):
     assert (b[leaf, :3].view(np.float32) == (v[2::3] - v[0::3])[prim]).all()                  # edge1 = v2 - v0
 
 
-def test_duplicates_grids_and_flat_scenes(ctx):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_duplicates_grids_and_flat_scenes(ctx, algo):
     tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     v = np.tile(tri, (500, 1))                                        # 500 identical triangles: all Morton keys equal
-    packed, _ = api.bvh_build_device(ctx, v, 3, np.arange(1500, dtype=np.uint32), 500)
+    packed, _ = api.bvh_build_device(ctx, v, 3, np.arange(1500, dtype=np.uint32), 500, algorithm=algo)
     _invariants(packed, 500)
     sc = scenes.terrain(20)                                           # flat-ish grid, many equal keys per axis
     fv, fi = sc.flat()
-    packed, _ = api.bvh_build_device(ctx, fv, 8, fi, sc.triangle_count)
+    packed, _ = api.bvh_build_device(ctx, fv, 8, fi, sc.triangle_count, algorithm=algo)
     _invariants(packed, sc.triangle_count)
     v8 = np.zeros((sc.verts.shape[0], 8), np.float32)
     v8[:, :3] = sc.verts
-    packed2, _ = api.bvh_build_device(ctx, v8, 8, sc.faces.reshape(-1), sc.triangle_count)   # indexed + stride 8
+    packed2, _ = api.bvh_build_device(ctx, v8, 8, sc.faces.reshape(-1), sc.triangle_count, algorithm=algo)   # indexed + stride 8
     assert (packed2 == packed).all()
 
 
-def test_larger_child_first_and_boxes_enclose(ctx):
+def test_ploc_is_deterministic_and_radius_is_a_knob(ctx):
+    """Internal node ids come from an atomic counter, the emitted stream does not depend on them: two builds are byte-equal.
+    Any radius gives a valid stream; radius 1 is plain neighbour merging."""
+    v, idx = _soup(20000, 21)
+    a, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)
+    b, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)
+    assert (a == b).all()
+    for radius in (1, 4, 64, 256):
+        p, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, radius=radius)
+        assert api.bvh_validate(p) == 20000
+    with pytest.raises(api.RtsError):
+        api.bvh_build_device(ctx, v, 3, idx, 20000, radius=1000)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_larger_child_first_and_boxes_enclose(ctx, algo):
     v, idx = _soup(2000, 9)
-    packed, _ = api.bvh_build_device(ctx, v, 3, idx, 2000)
+    packed, _ = api.bvh_build_device(ctx, v, 3, idx, 2000, algorithm=algo)
     N = 3999
     a, b = packed[0:2 * N:2], packed[1:2 * N:2]
     f = packed.view(np.float32)
@@ -82,9 +102,10 @@ def test_larger_child_first_and_boxes_enclose(ctx):
             assert (f[2 * i, :3] == np.minimum(llo, rlo)).all() and (f[2 * i + 1, :3] == np.maximum(lhi, rhi)).all()
 
 
-def test_trace_through_gpu_built_stream(ctx):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_trace_through_gpu_built_stream(ctx, algo):
     wl = workloads.prepare("atrium", 640, 360)
-    packed, ms = api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, install=True)
+    packed, ms = api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, install=True, algorithm=algo)
     assert api.bvh_validate(packed) == wl.prim_count and ctx.get_option("bvh_ordered") == 1
     lt = oracle.light_from_product(wl.light, wl.constants)
     want, V, L = oracle.shadow_mask(packed, wl.constants.as_array(), lt, wl.positions, wl.W, wl.H)
@@ -95,7 +116,9 @@ def test_trace_through_gpu_built_stream(ctx):
     ctx.set_option("kernel", -1)
     sah, Vs, Ls = oracle.shadow_mask(wl.packed, wl.constants.as_array(), lt, wl.positions, wl.W, wl.H)
     assert (want != sah).mean() < 1e-3          # same geometry, different tree: masks agree up to SURVEY B-6
-    print(f"LBVH build {ms:.2f} ms for {wl.prim_count} triangles; nodes/ray LBVH {V / want.size:.1f} vs SAH {Vs / want.size:.1f}")
+    print(f"{algo} build {ms:.2f} ms for {wl.prim_count} triangles; nodes/ray {V / want.size:.1f} vs SAH {Vs / want.size:.1f}")
+    if algo == "ploc":
+        assert V < 1.45 * Vs                      # the clustering tree stays near the SAH tree's traversal cost
 
 
 def test_error_codes(ctx):
