@@ -201,27 +201,30 @@ __global__ void plocInitKernel(Lbvh b, Ploc c, const uint32_t* order) {
     for (int a = 0; a < 3; ++a) { c.lo[(size_t)j * 3 + a] = b.leafLo[(size_t)prim * 3 + a]; c.hi[(size_t)j * 3 + a] = b.leafHi[(size_t)prim * 3 + a]; }
 }
 
-// Nearest neighbour within `radius` positions: smallest surface area of the union, ties to the lower position.  (The
-// pair with the globally smallest distance, lowest positions first, is always mutual: every round merges something.)
+// Nearest neighbour within `radius` positions: smallest surface area of the union; of equal areas the nearer position
+// wins, the lower one at equal distance (regular meshes are full of exact ties: preferring the far end of the window
+// pairs clusters across the grid and doubled the traversal cost of the atrium).  The pair with the globally smallest
+// area -- smallest gap, then lowest position among those -- is always mutual, so every round merges something.
 __global__ void plocNearestKernel(Ploc c) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n) return;
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) { lo[a] = c.lo[(size_t)i * 3 + a]; hi[a] = c.hi[(size_t)i * 3 + a]; }
-    const uint32_t first = i > c.radius ? i - c.radius : 0u;
-    const uint32_t last = i + c.radius < c.n ? i + c.radius : c.n - 1u;
     float best = __builtin_inff();
     uint32_t bestJ = END;
-    for (uint32_t j = first; j <= last; ++j) {
-        if (j == i) continue;
-        float ulo[3], uhi[3];
-        for (int a = 0; a < 3; ++a) {
-            const float l = c.lo[(size_t)j * 3 + a], h = c.hi[(size_t)j * 3 + a];
-            ulo[a] = l < lo[a] ? l : lo[a];
-            uhi[a] = h > hi[a] ? h : hi[a];
+    for (uint32_t d = 1; d <= c.radius; ++d) {
+        for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? i < d : i + d >= c.n) continue;
+            const uint32_t j = side == 0 ? i - d : i + d;
+            float ulo[3], uhi[3];
+            for (int a = 0; a < 3; ++a) {
+                const float l = c.lo[(size_t)j * 3 + a], h = c.hi[(size_t)j * 3 + a];
+                ulo[a] = l < lo[a] ? l : lo[a];
+                uhi[a] = h > hi[a] ? h : hi[a];
+            }
+            const float area = surfaceArea(ulo, uhi);
+            if (area < best || bestJ == END) { best = area; bestJ = j; }      // (also takes the first candidate when every area is inf/NaN)
         }
-        const float d = surfaceArea(ulo, uhi);
-        if (d < best || bestJ == END) { best = d; bestJ = j; }            // (also takes the first candidate when every area is inf/NaN)
     }
     c.nn[i] = bestJ;
 }
