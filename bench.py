@@ -99,19 +99,20 @@ def live_counters(args, say):
         return None
     work = tempfile.mkdtemp(prefix="rts_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--kernel", str(args.kernel)]
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--kernel", str(args.kernel),
+             "--prewarm-seconds", "0"]
     res = {"source": "live: rocprofv3 --pmc child passes of this command in this run", "passes": []}
     t_all = time.time()
     try:
         # pass 0: kernel trace (durations under the profiler, grid, registers)
         d = os.path.join(work, "trace")
-        r = subprocess.run([prof, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                           capture_output=True, text=True, timeout=240)
+        r = subprocess.run([prof, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child + ["--prewarm-seconds", "0.5"],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
         if r.returncode != 0:
             say(f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {r.stderr[-300:]}")
             return None
         manifest = json.loads(r.stdout.strip().splitlines()[-1])
-        n_cal, n_real = manifest["calib_launches"], manifest["real_launches"]
+        n_cal, n_pre, n_real = manifest["calib_launches"], manifest["prewarm_launches"], manifest["real_launches"]
         durs = []
         for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             with open(path, newline="") as fh:
@@ -119,10 +120,10 @@ def live_counters(args, say):
                     if "shadowMask" in row.get("Kernel_Name", ""):
                         durs.append((int(row["Dispatch_Id"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), row))
         durs.sort(key=lambda t: t[0])
-        if len(durs) != n_cal + n_real:
-            say(f"kernel trace has {len(durs)} shadow dispatches, expected {n_cal + n_real}: no live counters")
+        if len(durs) != n_cal + n_pre + n_real:
+            say(f"kernel trace has {len(durs)} shadow dispatches, expected {n_cal + n_pre + n_real}: no live counters")
             return None
-        real = [t[1] for t in durs[n_cal:]]
+        real = [t[1] for t in durs[n_cal + n_pre:]]
         row = durs[-1][2]
         res["kernel_trace"] = {"kernel": row["Kernel_Name"], "launches": n_real, "avg_ns": sum(real) / len(real),
                                "median_ns": sorted(real)[len(real) // 2],
@@ -139,7 +140,7 @@ def live_counters(args, say):
                 continue
             per = _per_dispatch(d)
             for name, vals in per.items():
-                if len(vals) != n_cal + n_real:
+                if len(vals) != n_cal + n_real:                 # (the counter passes run without a pre-warm)
                     continue
                 calib[name] = sum(vals[:n_cal]) / n_cal
                 counters[name] = sum(vals[n_cal:]) / n_real
@@ -190,13 +191,20 @@ def pmc_child(args):
             ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
         ctx.synchronize()
         ctx.set_bvh(wl.packed)
+        n_pre = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.prewarm_seconds:   # only the kernel-trace pass asks for one (durations)
+            for _ in range(50):
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            ctx.synchronize()
+            n_pre += 50
         for _ in range(n_real):
             ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
         ctx.synchronize()
         kname = ctx.last_kernel_name()
         ctx.free(d_pos)
         ctx.free(d_mask)
-    print(json.dumps({"calib_launches": n_cal, "real_launches": n_real, "kernel": kname,
+    print(json.dumps({"calib_launches": n_cal, "prewarm_launches": n_pre, "real_launches": n_real, "kernel": kname,
                       "calibration": {"known_read_bytes": W * H * 16 + 48, "known_write_bytes": W * H,
                                       "what": "same frame and light, BVH of one far-away triangle: reads = the position stream"}}))
 

@@ -17,7 +17,7 @@ def main():
         ctx.h2d(d_pos, wl.positions)
         for name, packed in (("one-triangle BVH", one), ("city BVH", wl.packed)):
             ctx.set_bvh(packed)
-            for kern in (0, 3, 4, 5, 8):
+            for kern in (0, 3, 4, 5):
                 for bw in (1, 4):
                     if kern == 0 and bw == 1:
                         continue
