@@ -360,6 +360,16 @@ def main():
     kernel_ms = float(per_launch.sum())
     median_ms = float(np.median(per_launch))
 
+    # ---- shader clock held under this load (diagnostics build of the same kernel, after the timed region) --------
+    clock_mhz = None
+    if kname.startswith("shadowMaskPacketKernel") and not striped and not args.no_probes:
+        try:
+            for _ in range(50):
+                one_step()
+            clock_mhz = ctx.measure_shader_clock_mhz(one_step, ((W + 7) // 8) * ((H + 7) // 8), launches=20)
+        except Exception as e:
+            say(f"clock measurement failed: {e!r}")
+
     # ---- the same dispatch against a one-triangle BVH: what the frame costs before any traversal ----------------
     floor_ms = float("nan")
     if not args.no_probes:
@@ -379,16 +389,6 @@ def main():
         floor_ms = float(np.median(fl))
         floor_ctx.close()
         ctx.h2d(d_mask, got)                                        # (the floor frames overwrote the mask)
-
-    # ---- shader clock held under this load (diagnostics build of the same kernel, after the timed region) --------
-    clock_mhz = None
-    if kname.startswith("shadowMaskPacketKernel") and not striped and not args.no_probes:
-        try:
-            for _ in range(50):
-                one_step()
-            clock_mhz = ctx.measure_shader_clock_mhz(one_step, ((W + 7) // 8) * ((H + 7) // 8))
-        except Exception as e:
-            say(f"clock measurement failed: {e!r}")
 
     if dist:
         import torch
