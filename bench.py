@@ -277,7 +277,7 @@ def main():
         shared_packed = buf.numpy().view(np.uint32)
     if dist:
         wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say,
-                               via_obj=False, packed=shared_packed)
+                               via_obj=False, packed=shared_packed, radius=workloads.SOFT_RADIUS.get(args.config, 0.01))
     else:
         wl = workloads.prepare_config(args.config, cache=True, threads=host_threads, log=say)
     rays_per_frame = wl.rays

@@ -19,15 +19,20 @@ CONFIGS = {
     "city_4k_soft16": ("city", 3840, 2160, "point", 16),      # configs[4]
     "courtyard_4k": ("courtyard", 3840, 2160, "point", 1),    # configs[2] on the San-Miguel-class stand-in (hard case)
     "courtyard_4k_soft16": ("courtyard", 3840, 2160, "point", 16),
+    "city_4k_soft16_wide": ("city", 3840, 2160, "point", 16),  # configs[4] with a five times larger light (SOFT_RADIUS)
     "calib_4k": ("calib", 3840, 2160, "point", 1),            # counter calibration only (see scenes.calib)
 }
+
+
+#: radius of the jittered light as a fraction of the scene's diagonal (default 1 %)
+SOFT_RADIUS = {"city_4k_soft16_wide": 0.05}
 
 
 class Workload:
     pass
 
 
-def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None, packed=None):
+def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None, packed=None, radius=0.01):
     say = log or (lambda *a: None)
     wl = Workload()
     t0 = time.time()
@@ -65,10 +70,10 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
     wl.nodes = nodes
     wl.positions = positions
     wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
-    return relight(wl, light, spp)
+    return relight(wl, light, spp, radius)
 
 
-def relight(wl, light="point", spp=1):
+def relight(wl, light="point", spp=1, radius=0.01):
     """The same scene, camera and G-buffer under another light / sample count (a shallow copy of `wl`)."""
     import copy
     wl = copy.copy(wl)
@@ -78,9 +83,9 @@ def relight(wl, light="point", spp=1):
         wl.light = None if spp <= 1 else api.Light.make(api.Light.DIRECTIONAL, sc.light_direction,
                                                         scenes.jitter_offsets(spp, 0.05))
     else:
-        radius = 0.01 * float(np.linalg.norm(sc.bbox_max - sc.bbox_min))
+        r = radius * float(np.linalg.norm(sc.bbox_max - sc.bbox_min))
         wl.light = api.Light.make(api.Light.POINT, sc.light_point,
-                                  scenes.jitter_offsets(spp, radius) if spp > 1 else None)
+                                  scenes.jitter_offsets(spp, r) if spp > 1 else None)
     wl.rays = wl.W * wl.H * max(1, spp)
     return wl
 
@@ -90,8 +95,9 @@ def prepare_config(name, cache=False, **kw):
     in the scene cache directory, keyed by the config, the generator source and the library build, so that the profiler
     passes of bench.py (child processes of one run) do not rebuild them."""
     scene, W, H, light, spp = CONFIGS[name]
+    radius = SOFT_RADIUS.get(name, 0.01)
     if not cache:
-        return prepare(scene, W, H, light=light, spp=spp, **kw)
+        return prepare(scene, W, H, light=light, spp=spp, radius=radius, **kw)
     import hashlib
     h = hashlib.sha256()
     h.update(repr((name, scene, W, H)).encode())
@@ -114,10 +120,10 @@ def prepare_config(name, cache=False, **kw):
             sc = wl.scene
             wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
             say(f"workload {name} loaded from {path}")
-            return relight(wl, light, spp)
+            return relight(wl, light, spp, radius)
         except Exception as e:                       # a torn or stale file: rebuild
             say(f"cache {path} unusable ({e!r}); rebuilding")
-    wl = prepare(scene, W, H, light=light, spp=spp, **kw)
+    wl = prepare(scene, W, H, light=light, spp=spp, radius=radius, **kw)
     tmp = f"{path}.{os.getpid()}.tmp.npz"
     np.savez(tmp, vertices=wl.vertices, indices=wl.indices, packed=wl.packed, positions=wl.positions,
              build_seconds=np.float64(wl.build_seconds))

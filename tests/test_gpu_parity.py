@@ -183,7 +183,10 @@ def test_config4_soft_shadows_16_samples(ctx):
     want = _check_workload(ctx, wl)
     assert want.max() == 16 and 0 < (want == 0).sum() and ((want > 0) & (want < 16)).sum() > 0   # penumbra exists
     wl = workloads.prepare("city", 960, 540, spp=16)
-    _check_workload(ctx, wl, variants=[0, 1])
+    narrow = _check_workload(ctx, wl, variants=[0, 1])
+    wide = _check_workload(ctx, workloads.relight(wl, "point", 16, radius=0.05))    # a five times larger light, every kernel
+    penumbra = lambda m: ((m > 0) & (m < 16)).mean()
+    assert penumbra(wide) > 2 * penumbra(narrow)
 
 
 @pytest.mark.parametrize("W,H", [(1, 1), (7, 5), (250, 131), (17, 300)])
