@@ -597,7 +597,9 @@ int orc_max_threads(void) {
 // do its 64 rays visit (what a wave-uniform sweep in increasing DFS index would iterate over),
 // against the longest single ray (what a lane-per-ray loop iterates over) and the sum.
 // out[0]=tiles, out[1]=sum of union sizes, out[2]=sum of per-tile max V, out[3]=sum of V,
-// out[4]=sum over union nodes that are leaves, out[5]=sum of lanes active over all sweep steps
+// out[4]=sum over union nodes that are leaves, out[5]=sum over union nodes that are the right sibling of the union node
+// visited just before them (a left child nobody entered, or a leaf: the sibling follows at once), out[6]=sum over union
+// nodes reached by a side-step (a miss link), out[7]=those of out[6] whose left sibling's subtree was walked in between
 // ---------------------------------------------------------------------------------------------
 extern "C" void orc_tile_union_stats(const uint32_t* packed, const float* constants, const void* light_v,
                                      const float* positions, uint32_t W, uint32_t H, uint64_t* out) {
@@ -609,10 +611,10 @@ extern "C" void orc_tile_union_stats_wh(const uint32_t* packed, const float* con
                                         const float* positions, uint32_t W, uint32_t H, uint32_t TW, uint32_t TH,
                                         uint64_t* out) {
     const OLight& lt = *(const OLight*)light_v;
-    uint64_t tiles = 0, sumU = 0, sumM = 0, sumV = 0, sumLeafU = 0;
+    uint64_t tiles = 0, sumU = 0, sumM = 0, sumV = 0, sumLeafU = 0, sumImm = 0, sumSide = 0;
     const uint32_t tx = W / TW, ty = H / TH;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : tiles, sumU, sumM, sumV, sumLeafU)
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : tiles, sumU, sumM, sumV, sumLeafU, sumImm, sumSide)
 #endif
     for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
         uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
@@ -646,8 +648,15 @@ extern "C" void orc_tile_union_stats_wh(const uint32_t* packed, const float* con
         visited.erase(std::unique(visited.begin(), visited.end()), visited.end());
         sumU += visited.size(); sumM += maxV; ++tiles;
         for (u32 n : visited) if (packed[(size_t)n * 8 + 3] != kInvalid) ++sumLeafU;
+        for (size_t k = 1; k < visited.size(); ++k) {
+            const u32 prev = visited[k - 1], cur = visited[k];
+            if (cur == prev + 1 && packed[(size_t)prev * 8 + 3] == kInvalid) continue;          // down-step into a left child
+            ++sumSide;                                                                          // reached through a miss link
+            const bool prevIsLeftChild = prev > 0 && packed[(size_t)(prev - 1) * 8 + 3] == kInvalid;
+            if (prevIsLeftChild && packed[(size_t)prev * 8 + 7] == cur) ++sumImm;                // ... of the node visited just before
+        }
     }
-    out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = sumLeafU; out[5] = 0;
+    out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = sumLeafU; out[5] = sumImm; out[6] = sumSide; out[7] = sumSide - sumImm;
 }
 
 // Experiment only: how many nodes would be visited if the children of an inner node were walked in another

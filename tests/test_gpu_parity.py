@@ -111,6 +111,19 @@ def test_config2_courtyard_4k_full_size_hard_scene(ctx):
         ctx.free(d_mask)
 
 
+def test_beyond_the_baseline_sizes_8k_frame_and_median_split_tree(ctx, city4k):
+    """Maximum sizes the harness reaches: the 999 488-triangle scene at 7680x4320 (33.2 M rays, 518 400 tiles per dispatch)
+    and the 1 034 288-triangle scene -- the builder's > 1 000 000-primitive median-split branch at the top
+    (BVHBuilder.cpp:157-178) -- at 3840x2160; default kernel and the plain loop."""
+    big = workloads.prepare("city", 7680, 4320, via_obj=False, packed=city4k.packed)
+    _check_workload(ctx, big, variants=[-1, 0])
+    assert ctx.last_kernel_name() in ("shadowMaskKernel<0>", "shadowMaskPacketKernel<1>")
+    del big
+    wl = workloads.prepare("city_big", 3840, 2160, via_obj=False)
+    assert wl.prim_count > 1000000
+    _check_workload(ctx, wl, variants=[-1, 0, 7])
+
+
 def test_config3_city_4k_row_striped_2_4_8(ctx, city4k):
     """BASELINE configs[3] at its own workload: the 3840x2160 frame of the ~1M-triangle scene cut into 2/4/8 row
     stripes, default kernel (the packet kernel), both partitions the multi-GPU path offers -- contiguous

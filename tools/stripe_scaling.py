@@ -1,0 +1,49 @@
+"""GPU box (one GPU): what the 1/2/4/8-GPU striped frame (BASELINE configs[3]) will cost per device.  Every stripe of an
+N-way partition is traced ALONE on this device, exactly as rank r of `bench.py --gpus N` would trace it (interleaved 32-row
+bands, one dispatch); the slowest stripe bounds the frame.  Prints the predicted strong-scaling efficiency
+t(1) / (N * max_r t(N, r)) -- a prediction from single-device timings, not a multi-GPU measurement."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="city_4k")
+    args = ap.parse_args()
+    from raytracedshadows_amd import api, workloads
+    wl = workloads.prepare_config(args.config, cache=True)
+    W, H = wl.W, wl.H
+    with api.ShadowContext(0) as ctx:
+        ctx.set_bvh(wl.packed)
+        d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+        ctx.h2d(d_pos, wl.positions)
+        base = None
+        for n in (1, 2, 4, 8):
+            worst, times = 0.0, []
+            for r in range(n):
+                def go():
+                    ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, r, light=wl.light)
+                for _ in range(300):
+                    go()
+                ts = []
+                for _ in range(40):
+                    ctx.timer_mark(0); go(); ctx.timer_mark(1)
+                    ts.append(ctx.timer_between_ms(0, 1))
+                times.append(float(np.median(ts)))
+            worst = max(times)
+            base = base or worst
+            print(f"[{args.config}] {n} stripe(s): per-stripe ms {' '.join(f'{t:.4f}' for t in times)}; slowest {worst:.4f} ms "
+                  f"-> {wl.rays / worst / 1e6:.1f} Grays/s aggregate, predicted efficiency {base / (n * worst) * 100:.0f} % ({ctx.last_kernel_name()})",
+                  flush=True)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
+if __name__ == "__main__":
+    main()
