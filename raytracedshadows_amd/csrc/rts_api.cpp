@@ -35,7 +35,8 @@ struct rts_ctx {
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
     uint32_t* d_tailQueue = nullptr;   // tail pass: 16 header words + tailCapacity entries of 4 words, header zero between frames
-    int tailPass = 0, tailBudget = 32, tailWaves = 4096;
+    int tailPass = 0, tailBudget = 64, tailWaves = 1024;
+    uint64_t tailFrames = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
 };
 
@@ -294,6 +295,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.tailCapacity = kTailCapacity;
         p.tailBudget = (uint32_t)c->tailBudget;
         p.tailWaves = (uint32_t)c->tailWaves;
+        p.tailParity = (uint32_t)(c->tailFrames++ & 1u);
     }
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {

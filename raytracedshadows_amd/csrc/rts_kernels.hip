@@ -191,7 +191,8 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
 // A piece that finds a hit writes 0 into the mask (the first launch wrote 1 for rays it had not seen occluded): any-hit
 // is an OR over the same set of tests, so the mask is unchanged.
 struct TailSink {
-    uint32_t* queue;            // TraceParams::tailQueue, NULL = no tail pass
+    uint32_t* queue;            // this frame's queue header (reserved, committed), NULL = no tail pass
+    uint32_t* entries;          // the queue's entries (4 words each)
     uint32_t capacity, budget;
     uint32_t pixel;             // this lane's pixel (index into the mask)
     bool handedOver = false;    // out: pieces were queued
@@ -229,7 +230,7 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
                 if (active) {
                     const uint32_t lane = laneId();
                     const uint64_t below = lane ? act & ((1ull << lane) - 1ull) : 0ull;
-                    uint32_t* e = sink->queue + 16u + (size_t)(base + (uint32_t)__builtin_popcountll(below)) * 4u;
+                    uint32_t* e = sink->entries + (size_t)(base + (uint32_t)__builtin_popcountll(below)) * 4u;
                     e[0] = ownerPixel; e[1] = node; e[2] = bound; e[3] = 0u;
                 }
                 // entries are reserved in order and every wave that finds room lies before every wave that does not, so
@@ -731,7 +732,11 @@ void shadowMaskPacketKernel(TraceParams p) {
         }
         if constexpr (TAIL && K == 1 && !SOFT) {
             TailSink sink;
-            sink.queue = p.tailQueue; sink.capacity = p.tailCapacity; sink.budget = p.tailBudget; sink.pixel = (uint32_t)pix[0];
+            // two queue headers, used alternately: the one of the previous frame is zeroed here (that frame's tail launch
+            // has finished: same stream), so no launch ever has to wait for, or count, its own waves
+            sink.queue = p.tailQueue + p.tailParity * 4u; sink.entries = p.tailQueue + 16u;
+            sink.capacity = p.tailCapacity; sink.budget = p.tailBudget; sink.pixel = (uint32_t)pix[0];
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2u) p.tailQueue[(p.tailParity ^ 1u) * 4u + threadIdx.x] = 0u;
             traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag, &sink);
         } else {
             traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
@@ -765,14 +770,14 @@ void shadowMaskPacketKernel(TraceParams p) {
 
 // Second launch of a frame traced with the tail pass: one queued piece per wave at a time.  The ray is made again from
 // the owner's texel (the same arithmetic, so the same ray), lane 0 starts on the piece and the other 63 lanes join through
-// the work sharing of traverseShare.  Only zeros are written, only where a hit is found.  The last wave to finish resets
-// the queue for the next frame.
+// the work sharing of traverseShare.  Only zeros are written, only where a hit is found.  (The queue header is reset by
+// the next frame's first launch, which uses the other header.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
 void shadowTailKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[1][64];
     const uint32_t lane = threadIdx.x & 63u;
     const NodeStream bvh = openStream(p);
-    uint32_t count = __hip_atomic_load(p.tailQueue + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // committed entries
+    uint32_t count = __hip_atomic_load(p.tailQueue + p.tailParity * 4u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // committed entries
     count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count < p.tailCapacity ? count : p.tailCapacity));
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t* e = p.tailQueue + 16u + (size_t)i * 4u;
@@ -786,10 +791,6 @@ void shadowTailKernel(TraceParams p) {
         else hit = traverseShare<false>(bvh, r, lane == 0u, node, shareSlots[0], nullptr, nullptr, bound);
         if (lane == 0u && hit) p.mask[pixel] = 0;                                             // comp:148: occluded
     }
-    uint32_t done = 0;
-    if (lane == 0u) done = __hip_atomic_fetch_add(p.tailQueue + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
-    if (done == gridDim.x - 1u && lane < 3u) __hip_atomic_store(p.tailQueue + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int VARIANT>

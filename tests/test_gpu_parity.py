@@ -437,8 +437,8 @@ def test_tuning_options_never_change_the_mask(ctx):
                 got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
                 assert (got == want).all(), ("tail_pass", budget, waves)
         ctx.set_option("tail_pass", 0)
-        ctx.set_option("tail_budget", 32)
-        ctx.set_option("tail_waves", 4096)
+        ctx.set_option("tail_budget", 64)
+        ctx.set_option("tail_waves", 1024)
         for kernel in (-1, 0, 3, 5, 7):                      # dispatch order of the tile rows: 2-D grids of every kernel family
             for order in (1, 2, 0):
                 ctx.set_option("kernel", kernel)
