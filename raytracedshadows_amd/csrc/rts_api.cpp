@@ -29,7 +29,7 @@ struct rts_ctx {
     const char* lastKernel = "";
     int packetBudget = 16;
     int packetShare = 4;
-    int packetGrowth = 0;
+    int packetGrowth = 0, packetGrowthDelay = 4;
     int blockWaves = 1;
     int ldsPad = 0;              // experiment knob: dynamic LDS bytes per workgroup (throttles occupancy)
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
@@ -67,6 +67,7 @@ int fillParams(rts_ctx* ctx, TraceParams& p) {
     p.packetBudget = (uint32_t)ctx->packetBudget;
     p.packetShare = (uint32_t)ctx->packetShare;
     p.packetGrowth = (uint32_t)ctx->packetGrowth;
+    p.packetGrowthDelay = (uint32_t)ctx->packetGrowthDelay;
     return RTS_OK;
 }
 
@@ -219,6 +220,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "packet_growth")) { if (value < 0 || value > 64) return RTS_ERR_INVALID_ARG; c->packetGrowth = value; return RTS_OK; }
+    if (!strcmp(key, "packet_growth_delay")) { if (value < 0 || value > 1024) return RTS_ERR_INVALID_ARG; c->packetGrowthDelay = value; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
@@ -240,6 +242,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "block_waves")) { *value = c->blockWaves; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
     if (!strcmp(key, "packet_growth")) { *value = c->packetGrowth; return RTS_OK; }
+    if (!strcmp(key, "packet_growth_delay")) { *value = c->packetGrowthDelay; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
     if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
     if (!strcmp(key, "tail_pass")) { *value = c->tailPass; return RTS_OK; }

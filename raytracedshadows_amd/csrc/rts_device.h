@@ -49,7 +49,8 @@ struct TraceParams {
     uint32_t tailBudget;      // lane-per-ray iterations a dissolved packet may spend before it hands its pieces to the tail pass
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
-    uint32_t packetGrowth;    // the share grows by packetGrowth/4 (sixteenths) per window the packet survives, up to 10/16
+    uint32_t packetGrowth;    // the share grows by packetGrowth/4 (sixteenths) per window the packet survives, up to 10/16 ...
+    uint32_t packetGrowthDelay; // ... starting after this many windows
     float offsets[64][4];
 };
 

@@ -499,8 +499,10 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     //  hundreds of side-steps covers a big union -- foliage, columns -- where a lane-per-ray iteration serves every ray
     //  that is alive at 2.5 times the cost of a packet step, so the packet has to serve more than 40 % of them to pay)
     const uint32_t window = p.packetBudget - 1u;
-    uint32_t thr = p.packetBudget * p.packetShare;
+    const uint32_t tbase = p.packetBudget * p.packetShare;
+    uint32_t thr = tbase;
     const uint32_t tinc = (p.packetBudget * p.packetGrowth) >> 2, tmax = p.packetBudget * (p.packetShare > 10u ? p.packetShare : 10u);
+    int32_t tv = (int32_t)tbase - (int32_t)(tinc * p.packetGrowthDelay);      // the growth starts after packetGrowthDelay windows
     int32_t budget = (int32_t)window;
     uint32_t acc = 0;
     bool leaf;
@@ -509,6 +511,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
         budget = __builtin_amdgcn_readfirstlane(budget);
         acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);
         thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr);
+        tv = __builtin_amdgcn_readfirstlane(tv);
 #pragma unroll
         for (int k = 0; k < K; ++k)
             members[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(members[k] >> 32)) << 32) |
@@ -518,7 +521,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)occluded[0]);
             // leaves are handled inside the asm loop; it only comes back when the packet is finished (cur == END),
             // dissolves, or (code 2) stands on a node nobody waits on after all its rays got occluded
-            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, tinc, tmax, window);
+            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, tv, tinc, tmax, tbase, window);
             if (code == 2) {
                 cur = waveMinU32(wait[0]);
                 members[0] = __builtin_amdgcn_ballot_w64(wait[0] == cur);
@@ -527,9 +530,9 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
             }
             leaf = false;
         } else if constexpr (PREFETCH && K == 1)
-            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, tinc, tmax, window) != 0;
+            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, tv, tinc, tmax, tbase, window) != 0;
         else
-            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, tinc, tmax, window) != 0;
+            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, tv, tinc, tmax, tbase, window) != 0;
         if (leaf) {
             // the packet stands on a leaf: one triangle, tested by the rays that are here
             const u32x8 n = nodes[cur];
