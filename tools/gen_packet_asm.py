@@ -122,7 +122,8 @@ def loop(K, form):
     L += ["s_mul_i32 s51, s51, %[thr]",
           "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
           "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
-          "s_min_i32 %[thr], %[thr], %[tmax]",                  # alive * window * share
+          "s_min_i32 %[thr], %[thr], %[tmax]",
+          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)                  # alive * window * share
           "s_lshl_b32 s50, %[acc], 4",                    # picked up * 16
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
@@ -197,6 +198,7 @@ def loop_prefetch(form):
           "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
           "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
           "s_min_i32 %[thr], %[thr], %[tmax]",
+          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)
           "s_lshl_b32 s50, %[acc], 4",
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
@@ -262,6 +264,7 @@ def loop_leaf(form):
           "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
           "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
           "s_min_i32 %[thr], %[thr], %[tmax]",
+          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)
           "s_lshl_b32 s50, %[acc], 4",
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
