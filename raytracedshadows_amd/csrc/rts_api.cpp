@@ -29,21 +29,15 @@ struct rts_ctx {
     const char* lastKernel = "";
     int packetBudget = 16;
     int packetShare = 4;
-    int packetGrowth = 0, packetGrowthDelay = 4;
     int blockWaves = 1;
     int ldsPad = 0;              // experiment knob: dynamic LDS bytes per workgroup (throttles occupancy)
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
-    uint32_t* d_tailQueue = nullptr;   // tail pass: 16 header words + tailCapacity entries of 4 words, header zero between frames
-    int tailPass = 0, tailBudget = 64, tailWaves = 1024;
-    uint64_t tailFrames = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
 };
 
 namespace {
-
-constexpr uint32_t kTailCapacity = 1u << 20;     // pieces the tail queue holds (16 MB); beyond it long waves simply walk on
 
 inline int hipStatus(hipError_t e) { return e == hipSuccess ? RTS_OK : RTS_ERR_HIP + (int)e; }
 #define RTS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipStatus(e_); } while (0)
@@ -66,8 +60,6 @@ int fillParams(rts_ctx* ctx, TraceParams& p) {
     p.bvhOrdered = (ctx->bvhFinite && ctx->bvhOrdered) ? 1u : 0u;
     p.packetBudget = (uint32_t)ctx->packetBudget;
     p.packetShare = (uint32_t)ctx->packetShare;
-    p.packetGrowth = (uint32_t)ctx->packetGrowth;
-    p.packetGrowthDelay = (uint32_t)ctx->packetGrowthDelay;
     return RTS_OK;
 }
 
@@ -160,7 +152,6 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_waveStats) (void)hipFree(c->d_waveStats);
     if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
-    if (c->d_tailQueue) (void)hipFree(c->d_tailQueue);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -204,23 +195,8 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "packet_budget")) { if (value < 1 || value > 4096) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
     if (!strcmp(key, "row_order")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->rowOrder = value; return RTS_OK; }
-    if (!strcmp(key, "tail_pass")) {
-        if (value != 0 && value != 1) return RTS_ERR_INVALID_ARG;
-        RTS_HIP(hipSetDevice(c->device));
-        if (value && !c->d_tailQueue) {
-            const size_t bytes = 64 + (size_t)kTailCapacity * 16;
-            RTS_HIP(hipMalloc((void**)&c->d_tailQueue, bytes));
-            RTS_HIP(hipMemset(c->d_tailQueue, 0, 64));
-        }
-        c->tailPass = value;
-        return RTS_OK;
-    }
-    if (!strcmp(key, "tail_budget")) { if (value < 1 || value > 100000) return RTS_ERR_INVALID_ARG; c->tailBudget = value; return RTS_OK; }
-    if (!strcmp(key, "tail_waves")) { if (value < 1 || value > 65536) return RTS_ERR_INVALID_ARG; c->tailWaves = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
-    if (!strcmp(key, "packet_growth")) { if (value < 0 || value > 64) return RTS_ERR_INVALID_ARG; c->packetGrowth = value; return RTS_OK; }
-    if (!strcmp(key, "packet_growth_delay")) { if (value < 0 || value > 1024) return RTS_ERR_INVALID_ARG; c->packetGrowthDelay = value; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
@@ -241,13 +217,8 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "packet_budget")) { *value = c->packetBudget; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { *value = c->blockWaves; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
-    if (!strcmp(key, "packet_growth")) { *value = c->packetGrowth; return RTS_OK; }
-    if (!strcmp(key, "packet_growth_delay")) { *value = c->packetGrowthDelay; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
     if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
-    if (!strcmp(key, "tail_pass")) { *value = c->tailPass; return RTS_OK; }
-    if (!strcmp(key, "tail_budget")) { *value = c->tailBudget; return RTS_OK; }
-    if (!strcmp(key, "tail_waves")) { *value = c->tailWaves; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
@@ -295,15 +266,6 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
-    // tail pass: the one-sample, one-tile-per-wave packet kernel only (the pieces carry a pixel, not a sample)
-    const bool oneSample = !light || light->nsamples <= 1;
-    if (c->tailPass && c->d_tailQueue && variant == rts::V_PACKET && c->blockWaves == 1 && oneSample && (uint64_t)W * H <= 0xFFFFFFFFull) {
-        p.tailQueue = c->d_tailQueue;
-        p.tailCapacity = kTailCapacity;
-        p.tailBudget = (uint32_t)c->tailBudget;
-        p.tailWaves = (uint32_t)c->tailWaves;
-        p.tailParity = (uint32_t)(c->tailFrames++ & 1u);
-    }
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;

@@ -42,15 +42,8 @@ struct TraceParams {
     const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
     uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
-    uint32_t* tailQueue;      // tail pass: two headers {reserved, committed} at words 0 and 4 (used alternately), entries (4 x u32) from word 16 on; or NULL
-    uint32_t tailParity;      // which header this frame uses
-    uint32_t tailCapacity;    // entries the queue holds
-    uint32_t tailWaves;       // one-wave workgroups of the tail launch
-    uint32_t tailBudget;      // lane-per-ray iterations a dissolved packet may spend before it hands its pieces to the tail pass
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
-    uint32_t packetGrowth;    // the share grows by packetGrowth/4 (sixteenths) per window the packet survives, up to 10/16 ...
-    uint32_t packetGrowthDelay; // ... starting after this many windows
     float offsets[64][4];
 };
 

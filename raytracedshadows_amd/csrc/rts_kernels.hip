@@ -184,24 +184,10 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
     uint64_t tDissolve = 0;     // clock when the (last) packet of this wave dissolved
 };
 
-// Tail pass (two launches per frame, optional): a dissolved packet that is still walking after `budget` iterations
-// writes its unfinished pieces -- {pixel of the owner ray, node, bound} -- to a queue and ends; a second, small launch
-// gives every piece a wave of its own, in which the range fans out over 64 lanes through the same work sharing.  The
-// time of a tile whose rays all scatter is otherwise the time of its longest ray (270 dependent iterations on atrium).
-// A piece that finds a hit writes 0 into the mask (the first launch wrote 1 for rays it had not seen occluded): any-hit
-// is an OR over the same set of tests, so the mask is unchanged.
-struct TailSink {
-    uint32_t* queue;            // this frame's queue header (reserved, committed), NULL = no tail pass
-    uint32_t* entries;          // the queue's entries (4 words each)
-    uint32_t capacity, budget;
-    uint32_t pixel;             // this lane's pixel (index into the mask)
-    bool handedOver = false;    // out: pieces were queued
-};
-
 template <bool FAST>
 __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
-                                              ShareDiag* diag = nullptr, TailSink* sink = nullptr, uint32_t firstBound = END) {
-    uint32_t node = live ? start : END, bound = firstBound, owner = laneId();
+                                              ShareDiag* diag = nullptr) {
+    uint32_t node = live ? start : END, bound = END, owner = laneId();
     uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
     // The loop is rotated: the node of the NEXT iteration is requested before the triangle of this one is tested.
@@ -218,30 +204,6 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
         const uint64_t act = __builtin_amdgcn_ballot_w64(active);
         if (act == 0) break;
         if (diag && diag->on) { diag->iterations += 1u; diag->laneSteps += (uint32_t)__builtin_popcountll(act); }
-        if (sink && sink->queue && iter >= sink->budget) {
-            // hand the unfinished pieces over to the tail pass (one atomic per wave); if the queue is full, walk on
-            const uint32_t n = (uint32_t)__builtin_popcountll(act);
-            uint32_t base = 0;
-            if (laneId() == (uint32_t)__builtin_ctzll(act))
-                base = __hip_atomic_fetch_add(sink->queue, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(act));
-            if (base + n <= sink->capacity) {
-                const uint32_t ownerPixel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)sink->pixel);
-                if (active) {
-                    const uint32_t lane = laneId();
-                    const uint64_t below = lane ? act & ((1ull << lane) - 1ull) : 0ull;
-                    uint32_t* e = sink->entries + (size_t)(base + (uint32_t)__builtin_popcountll(below)) * 4u;
-                    e[0] = ownerPixel; e[1] = node; e[2] = bound; e[3] = 0u;
-                }
-                // entries are reserved in order and every wave that finds room lies before every wave that does not, so
-                // the committed total is exactly the length of the written prefix
-                if (laneId() == (uint32_t)__builtin_ctzll(act))
-                    __hip_atomic_fetch_add(sink->queue + 1, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sink->handedOver = true;
-                break;
-            }
-            sink->queue = nullptr;                                   // full: this wave walks on (the reservation is never used)
-        }
         uint32_t next = node;                                        // lanes that do not move keep their (finished) range
         if ((iter++ & 3u) == 0) {
             const uint64_t idle = ~act;
@@ -444,8 +406,7 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], uint32_t* lds,
-                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr,
-                                               TailSink* sink = nullptr) {
+                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr) {
     // (the stream's address as an explicitly wave-uniform value: when this function is inlined into a loop over tiles the
     //  compiler may keep the kernel argument in VGPRs, which the asm's scalar loads cannot take)
     const uint64_t bvhAddr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)p.bvh >> 32)) << 32) |
@@ -495,14 +456,8 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     // below p.packetShare/16 of them it is cheaper to let every ray continue alone (atrium: 92 % of the rays
     // die early and the rest scatter between the columns).
     uint32_t cur = 0;
-    // (the share grows with the packet's age, packetGrowth/4 sixteenths per window: a packet that is still walking after
-    //  hundreds of side-steps covers a big union -- foliage, columns -- where a lane-per-ray iteration serves every ray
-    //  that is alive at 2.5 times the cost of a packet step, so the packet has to serve more than 40 % of them to pay)
     const uint32_t window = p.packetBudget - 1u;
-    const uint32_t tbase = p.packetBudget * p.packetShare;
-    uint32_t thr = tbase;
-    const uint32_t tinc = (p.packetBudget * p.packetGrowth) >> 2, tmax = p.packetBudget * (p.packetShare > 10u ? p.packetShare : 10u);
-    int32_t tv = (int32_t)tbase - (int32_t)(tinc * p.packetGrowthDelay);      // the growth starts after packetGrowthDelay windows
+    const uint32_t thr = p.packetBudget * p.packetShare;
     int32_t budget = (int32_t)window;
     uint32_t acc = 0;
     bool leaf;
@@ -510,8 +465,6 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
         budget = __builtin_amdgcn_readfirstlane(budget);
         acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);
-        thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr);
-        tv = __builtin_amdgcn_readfirstlane(tv);
 #pragma unroll
         for (int k = 0; k < K; ++k)
             members[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(members[k] >> 32)) << 32) |
@@ -521,7 +474,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)occluded[0]);
             // leaves are handled inside the asm loop; it only comes back when the packet is finished (cur == END),
             // dissolves, or (code 2) stands on a node nobody waits on after all its rays got occluded
-            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, tv, tinc, tmax, tbase, window);
+            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window);
             if (code == 2) {
                 cur = waveMinU32(wait[0]);
                 members[0] = __builtin_amdgcn_ballot_w64(wait[0] == cur);
@@ -530,9 +483,9 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
             }
             leaf = false;
         } else if constexpr (PREFETCH && K == 1)
-            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, tv, tinc, tmax, tbase, window) != 0;
+            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, window) != 0;
         else
-            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, tv, tinc, tmax, tbase, window) != 0;
+            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, window) != 0;
         if (leaf) {
             // the packet stands on a leaf: one triangle, tested by the rays that are here
             const u32x8 n = nodes[cur];
@@ -573,7 +526,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
-            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag, K == 1 ? sink : nullptr);
+            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
             result[k] = result[k] || h;
         }
     }
@@ -691,8 +644,7 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // SOFT = more than one sample per pixel: only then the G-buffer position has to stay in registers across the walk.
 // PLAIN = the everyday launch (natural tile order on a 2-D grid, one contiguous row range, no diagnostics): the scalar
 // prologue that sorts out the other cases is compiled away.
-// TAIL = dissolved packets hand their unfinished pieces to the tail pass after p.tailBudget iterations (K = 1, one sample).
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, bool TAIL = false>
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
@@ -738,17 +690,7 @@ void shadowMaskPacketKernel(TraceParams p) {
             asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
             tReady = __builtin_amdgcn_s_memtime();
         }
-        if constexpr (TAIL && K == 1 && !SOFT) {
-            TailSink sink;
-            // two queue headers, used alternately: the one of the previous frame is zeroed here (that frame's tail launch
-            // has finished: same stream), so no launch ever has to wait for, or count, its own waves
-            sink.queue = p.tailQueue + p.tailParity * 4u; sink.entries = p.tailQueue + 16u;
-            sink.capacity = p.tailCapacity; sink.budget = p.tailBudget; sink.pixel = (uint32_t)pix[0];
-            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2u) p.tailQueue[(p.tailParity ^ 1u) * 4u + threadIdx.x] = 0u;
-            traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag, &sink);
-        } else {
-            traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
-        }
+        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -773,31 +715,6 @@ void shadowMaskPacketKernel(TraceParams p) {
         o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
                ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);
         o[3] = ((uint64_t)bx << 48) | ((uint64_t)(by & 0xFFFFu) << 32) | shareDiag.laneSteps;   // ... and the lane-steps in them
-    }
-}
-
-// Second launch of a frame traced with the tail pass: one queued piece per wave at a time.  The ray is made again from
-// the owner's texel (the same arithmetic, so the same ray), lane 0 starts on the piece and the other 63 lanes join through
-// the work sharing of traverseShare.  Only zeros are written, only where a hit is found.  (The queue header is reset by
-// the next frame's first launch, which uses the other header.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
-void shadowTailKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[1][64];
-    const uint32_t lane = threadIdx.x & 63u;
-    const NodeStream bvh = openStream(p);
-    uint32_t count = __hip_atomic_load(p.tailQueue + p.tailParity * 4u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // committed entries
-    count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count < p.tailCapacity ? count : p.tailCapacity));
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const uint32_t* e = p.tailQueue + 16u + (size_t)i * 4u;
-        const uint32_t pixel = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
-        const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]);
-        const uint32_t bound = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[2]);
-        const f32x4 t = *((const f32x4*)p.positions + pixel);                                 // comp:135 (same texel for every lane)
-        const Ray r = makeShadowRay(p, F3{ t.x, t.y, t.z }, 0u);
-        bool hit;
-        if (p.bvhFinite && raySafe(r)) hit = traverseShare<true>(bvh, r, lane == 0u, node, shareSlots[0], nullptr, nullptr, bound);
-        else hit = traverseShare<false>(bvh, r, lane == 0u, node, shareSlots[0], nullptr, nullptr, bound);
-        if (lane == 0u && hit) p.mask[pixel] = 0;                                             // comp:148: occluded
     }
 }
 
@@ -866,12 +783,7 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         switch (variant) {
         case V_PACKET:
             if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
-            else if (p.tailQueue) {                  // two launches: the frame, then the pieces the long waves handed over
-                if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
-                    hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, true>), grid, b1, ldsPad, stream, p);
-                else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, true>), grid, b1, ldsPad, stream, p);
-                hipLaunchKernelGGL(shadowTailKernel, dim3(p.tailWaves), b1, 0, stream, p);
-            } else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
+            else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
             else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);
             break;

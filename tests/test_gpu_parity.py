@@ -428,17 +428,6 @@ def test_tuning_options_never_change_the_mask(ctx):
     ctx.set_bvh(wl.packed)
     defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel", "row_order")}
     try:
-        for budget in (1, 3, 32):                            # tail pass: long waves hand their pieces to a second launch
-            ctx.set_option("kernel", -1)
-            ctx.set_option("tail_pass", 1)
-            ctx.set_option("tail_budget", budget)
-            for waves in (1, 64, 4096):
-                ctx.set_option("tail_waves", waves)
-                got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
-                assert (got == want).all(), ("tail_pass", budget, waves)
-        ctx.set_option("tail_pass", 0)
-        ctx.set_option("tail_budget", 64)
-        ctx.set_option("tail_waves", 1024)
         for kernel in (-1, 0, 3, 5, 7):                      # dispatch order of the tile rows: 2-D grids of every kernel family
             for order in (1, 2, 0):
                 ctx.set_option("kernel", kernel)

@@ -119,11 +119,7 @@ def loop(K, form):
               f"s_or_b64 s[48:49], s[48:49], %[m{k}]",   # ... or walk with the packet
               "s_bcnt1_i32_b64 s50, s[48:49]",
               "s_add_u32 s51, s51, s50" if k else "s_mov_b32 s51, s50"]
-    L += ["s_mul_i32 s51, s51, %[thr]",
-          "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
-          "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
-          "s_min_i32 %[thr], %[thr], %[tmax]",
-          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)                  # alive * window * share
+    L += ["s_mul_i32 s51, s51, %[thr]",                  # alive * window * share
           "s_lshl_b32 s50, %[acc], 4",                    # picked up * 16
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
@@ -195,10 +191,6 @@ def loop_prefetch(form):
           "s_or_b64 s[48:49], s[48:49], %[m0]",
           "s_bcnt1_i32_b64 s51, s[48:49]",
           "s_mul_i32 s51, s51, %[thr]",
-          "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
-          "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
-          "s_min_i32 %[thr], %[thr], %[tmax]",
-          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)
           "s_lshl_b32 s50, %[acc], 4",
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
@@ -261,10 +253,6 @@ def loop_leaf(form):
           "s_or_b64 s[48:49], s[48:49], %[m0]",
           "s_bcnt1_i32_b64 s51, s[48:49]",
           "s_mul_i32 s51, s51, %[thr]",
-          "s_add_i32 %[tv], %[tv], %[tinc]",              # the longer a packet has walked, the stricter the rule:
-          "s_max_i32 %[thr], %[tv], %[tbase]",            # thr = clamp(tv, base, max), tv starts below base (a delay)
-          "s_min_i32 %[thr], %[thr], %[tmax]",
-          "s_nop 0",                                      # (keeps the code behind this block on its 8-byte phase: +2 % otherwise)
           "s_lshl_b32 s50, %[acc], 4",
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
@@ -354,13 +342,13 @@ def emit_asm(K, form, ind, prefetch=False, leaf=False):
     lines = loop_leaf(form) if leaf else (loop_prefetch(form) if prefetch else loop(K, form))
     lines = [relocate(l) for l in lines]
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
-    outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[thr] "+s"(thr)', '[tv] "+s"(tv)', '[leaf] "=&s"(leaf)']
+    outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
     outs += [f'[m{k}] "+s"(members[{k}])' for k in range(K)]
     outs += [f'[w{k}] "+v"(wait[{k}])' for k in range(K)]
     outs += [f'[t{i}] "=&v"(t{i})' for i in range(15 if leaf else 7)]
     if leaf:
         outs += ['[oc0] "+s"(occluded[0])']
-    ins = ['[base] "s"(base)', '[tinc] "s"(tinc)', '[tmax] "s"(tmax)', '[tbase] "s"(tbase)', '[window] "s"(window)']
+    ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
     for k in range(K):
         ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
         if leaf:
@@ -380,14 +368,13 @@ def main():
          "// until the packet stands on a leaf (returns 1, cur = that leaf), runs out of nodes (returns 0, cur = END)",
          "// or decides to dissolve (returns 0, cur = node to continue at).  Dissolve rule: every `window`+1 side-steps",
          "// the rays picked up at those side-steps (`acc`) are compared with the rays alive: acc*16 < alive*thr with",
-         "// thr = (window+1)*share dissolves the packet; tv grows by tinc per window survived, thr = clamp(tv, tbase, tmax).",
+         "// thr = (window+1)*share dissolves the packet.",
          "// form 0..7: ordered slab test for the sign octant (bit a set <=> 1/d component a negative in every lane);",
          "// form 8: generic FAST slab test.", ""]
     for K in (1, 2, 4):
         o.append(f"__device__ __forceinline__ uint32_t packetDescend(uint32_t form, const void* base, const Ray (&r)[{K}],")
         o.append(f"                                                uint32_t& cur, uint64_t (&members)[{K}], uint32_t (&wait)[{K}],")
-        o.append("                                                int32_t& budget, uint32_t& acc, uint32_t& thr, int32_t& tv, uint32_t tinc, uint32_t tmax,")
-        o.append("                                                uint32_t tbase, uint32_t window) {")
+        o.append("                                                int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
         o.append("    uint32_t leaf;")
         o.append("    float t0, t1, t2, t3, t4, t5, t6;")
         o.append("    switch (form) {")
@@ -403,8 +390,7 @@ def main():
     o.append("__device__ __forceinline__ uint32_t packetDescendLeaf(uint32_t form, const void* base, const Ray (&r)[1],")
     o.append("                                                    uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
     o.append("                                                    uint64_t (&occluded)[1], int32_t& budget, uint32_t& acc,")
-    o.append("                                                    uint32_t& thr, int32_t& tv, uint32_t tinc, uint32_t tmax, uint32_t tbase,")
-    o.append("                                                    uint32_t window) {")
+    o.append("                                                    uint32_t thr, uint32_t window) {")
     o.append("    uint32_t leaf;")
     o.append("    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;")
     o.append("    switch (form) {")
@@ -419,8 +405,7 @@ def main():
     o.append("// K = 1 with the sequential successor node prefetched into a second SGPR set (see loop_prefetch).")
     o.append("__device__ __forceinline__ uint32_t packetDescendPrefetch(uint32_t form, const void* base, const Ray (&r)[1],")
     o.append("                                                        uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
-    o.append("                                                        int32_t& budget, uint32_t& acc, uint32_t& thr, int32_t& tv, uint32_t tinc, uint32_t tmax,")
-    o.append("                                                        uint32_t tbase, uint32_t window) {")
+    o.append("                                                        int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
     o.append("    uint32_t leaf;")
     o.append("    float t0, t1, t2, t3, t4, t5, t6;")
     o.append("    switch (form) {")
