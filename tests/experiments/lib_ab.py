@@ -1,5 +1,5 @@
-"""Experiment (GPU box): two builds of librts.so on the same box, alternating processes (RTS_LIB selects the build).
-usage: python tests/experiments/lib_ab.py <lib A> <lib B> [config ...]"""
+"""Experiment (GPU box): several builds of librts.so on the same box, alternating processes (RTS_LIB selects the build).
+usage: python tests/experiments/lib_ab.py <lib A>,<lib B>[,...] [config ...]"""
 import json
 import os
 import subprocess
@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def main():
-    libs = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
-    configs = sys.argv[3:] or ["city_4k"]
+    libs = [os.path.abspath(x) for x in sys.argv[1].split(",")]
+    configs = sys.argv[2:] or ["city_4k"]
     res = {}
     for rnd in range(3):
         for lib in libs:
