@@ -1,4 +1,4 @@
-"""Soak (GPU box): random large frames (packet kernels at full occupancy) on terrain / atrium / cornell scenes with random
+"""Soak (GPU box): random large frames (packet kernels at full occupancy) on terrain / atrium / cornell / courtyard scenes with random
 cameras, lights, sample counts, tuning knobs and stripe layouts, each mask against the oracle, for a fixed time."""
 import os, sys, time
 import numpy as np
@@ -13,13 +13,16 @@ t0 = time.time()
 cases = 0
 with api.ShadowContext(0) as ctx:
     while time.time() - t0 < budget:
-        kind = rs.randint(0, 3)
-        sc = scenes.terrain(int(rs.choice([40, 90, 160]))) if kind == 0 else (scenes.cornell() if kind == 1 else scenes.SCENES["atrium"]())
+        kind = rs.randint(0, 8)
+        sc = scenes.terrain(int(rs.choice([40, 90, 160]))) if kind < 3 else (scenes.cornell() if kind < 5 else
+                                                                              scenes.SCENES["atrium"]() if kind < 7 else scenes.courtyard())
         verts, idx = sc.flat()
         packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes
         lo, hi = sc.bbox_min, sc.bbox_max
         W, H = int(rs.randint(520, 1500)), int(rs.randint(500, 900))
         eye = (hi + (hi - lo) * rs.random_sample(3) * 0.5 + 1).astype(np.float32)
+        if sc.name == "courtyard" and rs.rand() < 0.7:                      # mostly from inside, under the trees
+            eye = (lo + (hi - lo) * np.array([0.1 + 0.8 * rs.rand(), 0.12, 0.1 + 0.8 * rs.rand()])).astype(np.float32)
         target = (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32)
         pos, _ = api.primary_positions(packed, eye, target, 1.0, W, H)
         k = api.RayTracingConstants.make(eye, [0.3, 0.8, 0.5], W, H)
@@ -37,6 +40,7 @@ with api.ShadowContext(0) as ctx:
                 ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
                 ctx.set_option("block_waves", int(rs.choice([1, 4])))
                 ctx.set_option("xcd_swizzle", int(rs.randint(0, 2)))
+                ctx.set_option("row_order", int(rs.randint(0, 3)))
                 got = np.full((H, W), 7, np.uint8)
                 ctx.h2d(d_mask, got)
                 n = int(rs.choice([1, 1, 2, 3, 5]))
@@ -52,7 +56,7 @@ with api.ShadowContext(0) as ctx:
                 assert bad == 0, (cases, sc.name, W, H, kernel, spp, n, bad)
         finally:
             ctx.free(d_pos); ctx.free(d_mask)
-            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0)):
+            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0)):
                 ctx.set_option(key, v)
         cases += 1
         if cases % 5 == 0:
