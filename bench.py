@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
     ap.add_argument("--no-probes", action="store_true",
                     help="skip the dispatch-floor and shader-clock probes (profiler runs: only the timed kernel is launched)")
+    ap.add_argument("--save-counters", default="", help="write the live counter passes to this JSON file (the committed fallback "
+                                                          "profiles/**/counters_<config>.json that is used when rocprofv3 is not available)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -432,6 +434,10 @@ def main():
             "shader_clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
             "note": "frac = the larger of two measured bounds (see the module docstring); algorithmic_* is SURVEY 8d's "
                     "cache-oblivious 32V+16L+17 B/ray from the oracle's exact visit counts, informational"}
+    if counters and args.save_counters:
+        rec = dict(counters, source_hash=source_hash(), workload=args.config, kernel=kname)
+        with open(args.save_counters, "w") as fh:
+            json.dump(rec, fh, indent=1)
     if N == 1 and counters is None and not args.no_pmc:
         counters = committed_counters(kname, args.config, say)
     hbm = issue = None

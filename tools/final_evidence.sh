@@ -8,7 +8,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gputests.log 2>&1; 
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 # the driver's command, then the long form
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_city4k_20_5.json 2> $OUT/bench_city4k_20_5.err; echo "bench 20/5 rc=$?"; cut -c1-260 $OUT/bench_city4k_20_5.json
-timeout -k 10 400 python bench.py > $OUT/bench_city4k.json 2> $OUT/bench_city4k.err; echo "bench rc=$?"
+timeout -k 10 400 python bench.py --save-counters $OUT/counters_city_4k.json > $OUT/bench_city4k.json 2> $OUT/bench_city4k.err; echo "bench rc=$?"
 for CFG in courtyard_4k atrium_1080p cornell_256 city_4k_soft16 courtyard_4k_soft16; do
   timeout -k 10 400 python bench.py --config $CFG > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err; echo "bench $CFG rc=$?"; cut -c1-200 $OUT/bench_$CFG.json
 done
