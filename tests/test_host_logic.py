@@ -104,3 +104,18 @@ def test_bvh_blob_round_trip(tmp_path):
     open(path, "r+b").write(b"XXXX")
     with pytest.raises(api.RtsError):
         api.load_bvh(path)
+
+
+def test_committed_counter_summary_belongs_to_this_kernel_build():
+    """bench.py falls back to profiles/**/counters_<config>.json when rocprofv3 is not available; the file is only used
+    if its kernel-source hash matches the sources in the tree.  A kernel change without a fresh profile fails here."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = bench.committed_counters("shadowMaskPacketKernel<1>", "city_4k", lambda *a: None)
+    assert rec is not None, "profiles/**/counters_city_4k.json is missing or belongs to another kernel build: re-run tools/final_evidence.sh"
+    c = rec["counters_per_launch"]
+    assert c["SQ_WAVES"] == 129600 and 1.0e8 < c["SQ_INSTS_VALU"] < 2.0e8 and c["FETCH_SIZE"] > 0 and c["WRITE_SIZE"] > 0
