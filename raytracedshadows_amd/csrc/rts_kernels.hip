@@ -736,8 +736,9 @@ __global__ __launch_bounds__(256) void maskFillKernel(TraceParams p, uint32_t ro
     if (x >= p.W || v >= rows) return;
     const uint32_t y = ownedRow(p, v);
     if (y >= p.rowEnd) return;
+    // (write-through stores: no XCD's L2 keeps a line of the mask, so that the slices' peeks are served from memory)
     uint8_t* o = p.mask + (size_t)y * p.W + x;
-    for (uint32_t k = 0; k < 4u && x + k < p.W; ++k) o[k] = 1;
+    for (uint32_t k = 0; k < 4u && x + k < p.W; ++k) __hip_atomic_store(o + k, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))

@@ -498,10 +498,12 @@ def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
     ctx.set_bvh(shrunk)
     assert ctx.get_option("slice_levels") == 0
     ctx.set_option("slices", 4)
+    ctx.set_option("kernel", 3)
     want, _, _ = oracle.shadow_mask(shrunk, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants),
                                     wl.positions, wl.W, wl.H)
     got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
     ctx.set_option("slices", 1)
+    ctx.set_option("kernel", -1)
     assert (got == want).all() and ctx.last_kernel_name() == "shadowMaskPacketKernel<1>"
 
 
