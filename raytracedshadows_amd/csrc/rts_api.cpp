@@ -34,10 +34,6 @@ struct rts_ctx {
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
-    // sliced launches (small frames): subtree ranges below the top of the tree, 0 = the stream cannot be sliced
-    int sliceLevels = 0;               // 1: two ranges, 2: four
-    uint32_t slice2[2][2] = {}, slice4[4][2] = {};
-    int slices = 0;                    // option: 0 = auto by launch size, 1 = never, 2 / 4 = always when possible
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
 };
 
@@ -53,46 +49,6 @@ int ensure(void** p, size_t* have, size_t want) {
     if (e != hipSuccess) { *p = nullptr; return hipStatus(e); }
     *have = want;
     return RTS_OK;
-}
-
-// Subtree ranges for sliced launches (rts_kernels.hip, shadowMaskSlicedKernel).  `node(i, w)` reads the 8 words of node i.
-// A range may start below node q only if q is an inner node whose box encloses the boxes of both its children and both
-// children are inner nodes (a leaf's triangle test is not implied by anything): then "child box hit => q's box hit".
-template <typename NodeFn>
-void buildSlices(rts_ctx* c, uint64_t N, NodeFn node) {
-    c->sliceLevels = 0;
-    auto splittable = [&](uint32_t q, uint32_t* l, uint32_t* r) -> bool {
-        uint32_t w[8], a[8], b[8];
-        if (q + 1 >= N) return false;
-        node(q, w);
-        if (w[3] != 0xFFFFFFFFu) return false;
-        *l = q + 1;
-        node(*l, a);
-        *r = a[7];
-        if (*r == 0xFFFFFFFFu || *r >= N) return false;
-        node(*r, b);
-        if (a[3] != 0xFFFFFFFFu || b[3] != 0xFFFFFFFFu) return false;
-        for (int k = 0; k < 3; ++k) {
-            float qlo, qhi, alo, ahi, blo, bhi;
-            memcpy(&qlo, &w[k], 4); memcpy(&qhi, &w[4 + k], 4);
-            memcpy(&alo, &a[k], 4); memcpy(&ahi, &a[4 + k], 4); memcpy(&blo, &b[k], 4); memcpy(&bhi, &b[4 + k], 4);
-            if (!(qlo <= alo && qlo <= blo && qhi >= ahi && qhi >= bhi)) return false;
-        }
-        return true;
-    };
-    uint32_t l, r;
-    if (!splittable(0, &l, &r)) return;
-    uint32_t rootNext = 0xFFFFFFFFu;
-    c->slice2[0][0] = l; c->slice2[0][1] = r;             // [left, right)  = the left subtree
-    c->slice2[1][0] = r; c->slice2[1][1] = rootNext;      // [right, END)   = the right subtree
-    c->sliceLevels = 1;
-    uint32_t ll, lr, rl, rr;
-    if (!splittable(l, &ll, &lr) || !splittable(r, &rl, &rr)) return;
-    c->slice4[0][0] = ll; c->slice4[0][1] = lr;
-    c->slice4[1][0] = lr; c->slice4[1][1] = r;
-    c->slice4[2][0] = rl; c->slice4[2][1] = rr;
-    c->slice4[3][0] = rr; c->slice4[3][1] = rootNext;
-    c->sliceLevels = 2;
 }
 
 int fillParams(rts_ctx* ctx, TraceParams& p) {
@@ -228,7 +184,6 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     hipError_t e = hipMemcpy(d, packed, count * 16, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return hipStatus(e); }
     c->d_bvh = d; c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
-    buildSlices(c, N, [&](uint32_t i, uint32_t* w) { memcpy(w, &packed[2 * (size_t)i], 32); });
     return RTS_OK;
 }
 
@@ -240,7 +195,6 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "packet_budget")) { if (value < 1 || value > 4096) return RTS_ERR_INVALID_ARG; c->packetBudget = value; return RTS_OK; }
     if (!strcmp(key, "block_waves")) { if (value != 1 && value != 4) return RTS_ERR_INVALID_ARG; c->blockWaves = value; return RTS_OK; }
     if (!strcmp(key, "row_order")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->rowOrder = value; return RTS_OK; }
-    if (!strcmp(key, "slices")) { if (value != 0 && value != 1 && value != 2 && value != 4) return RTS_ERR_INVALID_ARG; c->slices = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
@@ -265,8 +219,6 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "packet_share")) { *value = c->packetShare; return RTS_OK; }
     if (!strcmp(key, "kernel_count")) { *value = rts::V_COUNT; return RTS_OK; }
     if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
-    if (!strcmp(key, "slices")) { *value = c->slices; return RTS_OK; }
-    if (!strcmp(key, "slice_levels")) { *value = c->sliceLevels; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
@@ -314,20 +266,6 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
-    // sliced launch: the one-sample packet kernel with one tile per workgroup, when asked for (slices = 2 / 4) and the
-    // stream allows it.  (slices = 0, auto, is "off" for now: see DESIGN.md 4.4 for the measurements.)
-    const bool oneSample = !light || light->nsamples <= 1;
-    int wantSlices = c->slices >= 2 ? c->slices : 1;
-    if (wantSlices == 4 && c->sliceLevels < 2) wantSlices = 2;
-    if (wantSlices == 2 && c->sliceLevels < 1) wantSlices = 1;
-    if (wantSlices > 1 && variant == rts::V_PACKET && c->blockWaves == 1 && oneSample && !c->swizzle && !p.tileOrder && !p.waveStats &&
-        p.blocksY * 8u <= 65535u && p.blocksY <= 65535u) {
-        p.nSlices = (uint32_t)wantSlices;
-        for (int z = 0; z < wantSlices; ++z) {
-            p.sliceFirst[z] = wantSlices == 2 ? c->slice2[z][0] : c->slice4[z][0];
-            p.sliceBound[z] = wantSlices == 2 ? c->slice2[z][1] : c->slice4[z][1];
-        }
-    }
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
         p.lightType = light->type;
@@ -339,7 +277,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.nsamples = 1;
         for (int i = 0; i < 3; ++i) p.light[i] = k->lightDirection[i];
     }
-    c->lastKernel = p.nSlices > 1 ? "shadowMaskSlicedKernel" : rts::kernelName(variant, true);
+    c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
     return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, (uint32_t)c->ldsPad));
 }
@@ -504,11 +442,6 @@ int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t 
     if (c->d_bvh) { void* old = c->d_bvh; c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; RTS_HIP(hipFree(old)); }
     c->d_bvh = d_packed;
     c->bvhVec4 = count; c->P = P; c->bvhFinite = true; c->bvhOrdered = true;
-    bool readOk = true;
-    buildSlices(c, 2ull * P - 1, [&](uint32_t i, uint32_t* w) {
-        if (hipMemcpy(w, (const char*)d_packed + (size_t)i * 32, 32, hipMemcpyDeviceToHost) != hipSuccess) { readOk = false; memset(w, 0, 32); }
-    });
-    if (!readOk) c->sliceLevels = 0;
     return RTS_OK;
 }
 

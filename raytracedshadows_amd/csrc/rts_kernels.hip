@@ -186,8 +186,8 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
 
 template <bool FAST>
 __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
-                                              ShareDiag* diag = nullptr, uint32_t firstBound = END) {
-    uint32_t node = live ? start : END, bound = firstBound, owner = laneId();
+                                              ShareDiag* diag = nullptr) {
+    uint32_t node = live ? start : END, bound = END, owner = laneId();
     uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
     // The loop is rotated: the node of the NEXT iteration is requested before the triangle of this one is tested.
@@ -406,8 +406,7 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], uint32_t* lds,
-                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr,
-                                               uint32_t first = 0u, uint32_t bound = END) {
+                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr) {
     // (the stream's address as an explicitly wave-uniform value: when this function is inlined into a loop over tiles the
     //  compiler may keep the kernel argument in VGPRs, which the asm's scalar loads cannot take)
     const uint64_t bvhAddr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)p.bvh >> 32)) << 32) |
@@ -430,7 +429,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     if (any == 0) return;
     if (!p.bvhFinite || unsafe != 0) {       // a NaN could occur somewhere in this wave: EXACT form, lane per ray
 #pragma unroll
-        for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], first, lds, nullptr, bound);
+        for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], 0u, lds);
         return;
     }
     // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test.  (1/d is finite and non-zero for
@@ -456,7 +455,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     // p.packetBudget side-steps the rays picked up per side-step are compared with the rays still alive:
     // below p.packetShare/16 of them it is cheaper to let every ray continue alone (atrium: 92 % of the rays
     // die early and the rest scatter between the columns).
-    uint32_t cur = first;
+    uint32_t cur = 0;
     const uint32_t window = p.packetBudget - 1u;
     const uint32_t thr = p.packetBudget * p.packetShare;
     int32_t budget = (int32_t)window;
@@ -475,7 +474,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)occluded[0]);
             // leaves are handled inside the asm loop; it only comes back when the packet is finished (cur == END),
             // dissolves, or (code 2) stands on a node nobody waits on after all its rays got occluded
-            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window, bound);
+            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window);
             if (code == 2) {
                 cur = waveMinU32(wait[0]);
                 members[0] = __builtin_amdgcn_ballot_w64(wait[0] == cur);
@@ -484,9 +483,9 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
             }
             leaf = false;
         } else if constexpr (PREFETCH && K == 1)
-            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, window, bound) != 0;
+            leaf = packetDescendPrefetch(form, bvhBase, r, cur, members, wait, budget, acc, thr, window) != 0;
         else
-            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, window, bound) != 0;
+            leaf = packetDescend(form, bvhBase, r, cur, members, wait, budget, acc, thr, window) != 0;
         if (leaf) {
             // the packet stands on a leaf: one triangle, tested by the rays that are here
             const u32x8 n = nodes[cur];
@@ -516,18 +515,18 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                 for (int k = 0; k < K; ++k) members[k] = __builtin_amdgcn_ballot_w64(wait[k] == cur);
             }
         }
-    } while (leaf && cur < bound);
-    const bool dissolve = cur < bound;
+    } while (leaf && cur != END);
+    const bool dissolve = cur != END;
 #pragma unroll
     for (int k = 0; k < K; ++k) result[k] = __builtin_amdgcn_inverse_ballot_w64(occluded[k]);
     if (sideStepsLeft) *sideStepsLeft = dissolve ? -1 : 0;
-    if (cur < bound) {
+    if (cur != END) {
         // dissolved (not coherent enough for a packet): every unfinished ray continues alone
         if (shareDiag && shareDiag->on) shareDiag->tDissolve = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
-            const bool h = traverseShare<true>(bvh, r[k], mine < bound, mine, lds, shareDiag, bound);
+            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
             result[k] = result[k] || h;
         }
     }
@@ -719,59 +718,6 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Sliced launch (small frames, stripes of a multi-GPU frame): when a launch has only a few waves per slot its time is the
-// time of its longest waves -- tiles whose 64 rays all walk long paths.  Any-hit is an OR over the
-// triangles a ray reaches, and the index range of a walk can be cut at the miss link of any subtree root: here every tile
-// is walked by nSlices waves, wave z taking the subtree(s) [sliceFirst[z], sliceBound[z]) below the top of the tree with
-// all 64 rays.  A ray starts on the subtree's root, whose box it tests itself; the ancestors' tests are implied: the
-// host only slices below nodes whose boxes enclose their children's (checked), every ray of the wave is NaN-free
-// (checked here, otherwise slice 0 walks the whole tree the usual way), and then "child box hit => parent box hit" because
-// subtraction, multiplication by 1/d and rounding are monotone.  The mask is filled with 1 first; a wave writes 0 where
-// its slice occludes the ray.  A ray that is occluded in one slice still walks the others: more work in total, spread
-// over more waves -- worth it only while the machine is not full.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maskFillKernel(TraceParams p, uint32_t rows) {
-    const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u, v = blockIdx.y;
-    if (x >= p.W || v >= rows) return;
-    const uint32_t y = ownedRow(p, v);
-    if (y >= p.rowEnd) return;
-    // (write-through stores: no XCD's L2 keeps a line of the mask, so that the slices' peeks are served from memory)
-    uint8_t* o = p.mask + (size_t)y * p.W + x;
-    for (uint32_t k = 0; k < 4u && x + k < p.W; ++k) __hip_atomic_store(o + k, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
-void shadowMaskSlicedKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[1][64];
-    const uint32_t lane = threadIdx.x & 63u, slice = blockIdx.z;
-    const uint32_t x = blockIdx.x * 8u + (lane & 7u);
-    const uint32_t y = ownedRow(p, blockIdx.y * 8u + (lane >> 3));
-    bool alive = (x < p.W) && (y < p.rowEnd);
-    const size_t pix = (size_t)y * p.W + x;
-    // Slices are dispatched one after the other (z is the slowest grid dimension), so when slice z > 0 of a tile starts,
-    // the earlier slices of that tile have usually finished: a ray whose byte is already 0 needs no further walk -- what the
-    // reference's early out does for it.  A stale 1 (the other wave has not finished, or its store is not visible yet)
-    // only costs the walk; nothing is ever concluded from a 1.
-    if (alive && slice != 0u) alive = __hip_atomic_load(p.mask + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const bool ll[1] = { alive };
-    F3 rel{ 0.f, 0.f, 0.f };
-    if (ll[0]) {
-        f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix);               // comp:135
-        rel = F3{ t.x, t.y, t.z };
-    }
-    const NodeStream bvh = openStream(p);
-    const Ray r[1] = { makeShadowRay(p, rel, 0u) };
-    uint32_t first = p.sliceFirst[slice], bound = p.sliceBound[slice];
-    if (!p.bvhFinite || __builtin_amdgcn_ballot_w64(ll[0] && !raySafe(r[0])) != 0) {          // a NaN could occur: no slicing for this tile
-        if (slice != 0u) return;
-        first = 0u; bound = END;
-    }
-    bool occluded[1];
-    traversePacket<1, false>(p, bvh, r, ll, occluded, shareSlots[0], nullptr, nullptr, first, bound);
-    if (ll[0] && occluded[0]) __hip_atomic_store(p.mask + pix, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // comp:148: occluded
-}
-
 template <int VARIANT>
 __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[4][64];
@@ -832,11 +778,6 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     dim3 grid(p.gridBlocks), block(256);
     if (p.grid2d) grid = dim3(p.blocksX, p.blocksY);
     const bool soft = p.nsamples > 1;
-    if (p.nSlices > 1) {                            // (the caller set blocksX/blocksY for 8x8 tiles, one wave each)
-        hipLaunchKernelGGL(maskFillKernel, dim3((p.W + 1023u) / 1024u, p.blocksY * 8u), dim3(256), 0, stream, p, p.blocksY * 8u);
-        hipLaunchKernelGGL(shadowMaskSlicedKernel, dim3(p.blocksX, p.blocksY, p.nSlices), dim3(64), 0, stream, p);
-        return hipGetLastError();
-    }
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {

@@ -41,7 +41,6 @@ with api.ShadowContext(0) as ctx:
                 ctx.set_option("block_waves", int(rs.choice([1, 4])))
                 ctx.set_option("xcd_swizzle", int(rs.randint(0, 2)))
                 ctx.set_option("row_order", int(rs.randint(0, 3)))
-                ctx.set_option("slices", int(rs.choice([1, 1, 2, 4])))
                 got = np.full((H, W), 7, np.uint8)
                 ctx.h2d(d_mask, got)
                 n = int(rs.choice([1, 1, 2, 3, 5]))
@@ -57,7 +56,7 @@ with api.ShadowContext(0) as ctx:
                 assert bad == 0, (cases, sc.name, W, H, kernel, spp, n, bad)
         finally:
             ctx.free(d_pos); ctx.free(d_mask)
-            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0), ("slices", 1)):
+            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0)):
                 ctx.set_option(key, v)
         cases += 1
         if cases % 5 == 0:

@@ -426,17 +426,8 @@ def test_tuning_options_never_change_the_mask(ctx):
     want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
                                     oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
     ctx.set_bvh(wl.packed)
-    defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel", "row_order", "slices")}
+    defaults = {k: ctx.get_option(k) for k in ("packet_budget", "packet_share", "block_waves", "xcd_swizzle", "kernel", "row_order")}
     try:
-        for n in (2, 4):                                     # sliced launches: every tile walked by 2 / 4 waves, one per top-level subtree
-            ctx.set_option("kernel", 3)
-            ctx.set_option("slices", n)
-            got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
-            assert ctx.last_kernel_name() == "shadowMaskSlicedKernel" and (got == want).all(), ("slices", n)
-            out = np.full((wl.H, wl.W), 9, np.uint8)         # ... also as row stripes: rows outside the stripe stay untouched
-            ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light, row_begin=64, row_end=200, out=out)
-            assert (out[64:200] == want[64:200]).all() and (out[:64] == 9).all() and (out[200:] == 9).all()
-        ctx.set_option("slices", 1)
         for kernel in (-1, 0, 3, 5, 7):                      # dispatch order of the tile rows: 2-D grids of every kernel family
             for order in (1, 2, 0):
                 ctx.set_option("kernel", kernel)
@@ -490,21 +481,6 @@ def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
             got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
             assert (got == want).all(), (ordered, v)
     ctx.set_option("kernel", -1)
-    # sliced launches need the top boxes to enclose their children's: a stream whose root box is too small is not sliced
-    ctx.set_bvh(wl.packed)
-    assert ctx.get_option("slice_levels") == 2
-    shrunk = wl.packed.copy()
-    shrunk.view(np.float32)[1, 0] -= np.float32(1.0)                      # root bboxMax.x below its children's
-    ctx.set_bvh(shrunk)
-    assert ctx.get_option("slice_levels") == 0
-    ctx.set_option("slices", 4)
-    ctx.set_option("kernel", 3)
-    want, _, _ = oracle.shadow_mask(shrunk, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants),
-                                    wl.positions, wl.W, wl.H)
-    got = ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light)
-    ctx.set_option("slices", 1)
-    ctx.set_option("kernel", -1)
-    assert (got == want).all() and ctx.last_kernel_name() == "shadowMaskPacketKernel<1>"
 
 
 def test_wave_stats_diagnostics_do_not_touch_the_output(ctx):
@@ -673,12 +649,10 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                 ctx.set_option("packet_budget", int(rs.choice([1, 2, 8, 50])))
                 ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
                 ctx.set_option("block_waves", int(rs.choice([1, 4])))
-                ctx.set_option("slices", int(rs.choice([1, 2, 4])))
                 got = ctx.trace_shadow_mask(k, pos, W, H, light=light)
                 bad = int((got != want).sum())
                 assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
     finally:
-        ctx.set_option("slices", 1)
         ctx.set_option("kernel", -1)
         ctx.set_option("packet_budget", 16)
         ctx.set_option("packet_share", 4)

@@ -70,9 +70,7 @@ def test_generic(k):
 # Every loop starts with the same two instructions: a packet that has no node left (cur == END) must never reach the
 # node load -- END * 32 wraps to byte offset 0xFFFFFFE0, 4 GiB - 32 B past the stream (the one scalar-load fault on
 # record).  All callers already guarantee cur != END; the guard makes it a property of the loop itself.
-# `bnd` is the end of the index range this packet walks: END (0xFFFFFFFF) for a whole tree, the miss link of a subtree
-# root for a slice of it (sliced launches); "finished" is everywhere `index >= bnd`, which END satisfies for any bound.
-ENTRY_GUARD = ["s_cmp_ge_u32 %[cur], %[bnd]",
+ENTRY_GUARD = ["s_cmp_eq_u32 %[cur], -1",
                "s_cbranch_scc1 6f"]
 
 
@@ -107,7 +105,7 @@ def loop(K, form):
               "s_or_b64 s[50:51], s[50:51], s[48:49]"]
     L += ["s_cbranch_scc1 5b",                          # (K == 1: SCC still comes from the s_and above)
           "s_lshl_b32 s52, s47, 5",                     # side-step: nobody entered the subtree
-          "s_cmp_ge_u32 s47, %[bnd]",
+          "s_cmp_eq_u32 s47, -1",
           "s_cbranch_scc1 6f"]
     for k in range(K):
         L.append(f"v_cmp_eq_u32 %[m{k}], s47, %[w{k}]")  # whoever waits on that node is the packet now
@@ -182,7 +180,7 @@ def loop_prefetch(form):
           "4:",                                          # side-step
           "s_waitcnt lgkmcnt(0)",                        # drain the stale prefetch before re-targeting s[56:63]
           "s_lshl_b32 s52, s47, 5",
-          "s_cmp_ge_u32 s47, %[bnd]",
+          "s_cmp_eq_u32 s47, -1",
           "s_cbranch_scc1 6f",
           "v_cmp_eq_u32 %[m0], s47, %[w0]",
           "s_bcnt1_i32_b64 s50, %[m0]",
@@ -244,7 +242,7 @@ def loop_leaf(form):
           "s_cbranch_scc1 5b",
           "4:",                                           # side-step to s47
           "s_lshl_b32 s52, s47, 5",
-          "s_cmp_ge_u32 s47, %[bnd]",
+          "s_cmp_eq_u32 s47, -1",
           "s_cbranch_scc1 6f",
           "v_cmp_eq_u32 %[m0], s47, %[w0]",
           "s_bcnt1_i32_b64 s50, %[m0]",
@@ -318,7 +316,7 @@ def loop_leaf(form):
           "v_mov_b32 %[w0], -1",
           "s_mov_b64 exec, s[48:49]",
           "s_lshl_b32 s52, s47, 5",
-          "s_cmp_ge_u32 s47, %[bnd]",
+          "s_cmp_eq_u32 s47, -1",
           "s_cbranch_scc1 6b",
           "v_cmp_eq_u32 %[m0], s47, %[w0]",
           "s_cmp_eq_u64 %[m0], 0",
@@ -350,7 +348,7 @@ def emit_asm(K, form, ind, prefetch=False, leaf=False):
     outs += [f'[t{i}] "=&v"(t{i})' for i in range(15 if leaf else 7)]
     if leaf:
         outs += ['[oc0] "+s"(occluded[0])']
-    ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)', '[bnd] "s"(bound)']
+    ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
     for k in range(K):
         ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
         if leaf:
@@ -376,7 +374,7 @@ def main():
     for K in (1, 2, 4):
         o.append(f"__device__ __forceinline__ uint32_t packetDescend(uint32_t form, const void* base, const Ray (&r)[{K}],")
         o.append(f"                                                uint32_t& cur, uint64_t (&members)[{K}], uint32_t (&wait)[{K}],")
-        o.append("                                                int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window, uint32_t bound) {")
+        o.append("                                                int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
         o.append("    uint32_t leaf;")
         o.append("    float t0, t1, t2, t3, t4, t5, t6;")
         o.append("    switch (form) {")
@@ -392,7 +390,7 @@ def main():
     o.append("__device__ __forceinline__ uint32_t packetDescendLeaf(uint32_t form, const void* base, const Ray (&r)[1],")
     o.append("                                                    uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
     o.append("                                                    uint64_t (&occluded)[1], int32_t& budget, uint32_t& acc,")
-    o.append("                                                    uint32_t thr, uint32_t window, uint32_t bound) {")
+    o.append("                                                    uint32_t thr, uint32_t window) {")
     o.append("    uint32_t leaf;")
     o.append("    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;")
     o.append("    switch (form) {")
@@ -407,7 +405,7 @@ def main():
     o.append("// K = 1 with the sequential successor node prefetched into a second SGPR set (see loop_prefetch).")
     o.append("__device__ __forceinline__ uint32_t packetDescendPrefetch(uint32_t form, const void* base, const Ray (&r)[1],")
     o.append("                                                        uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
-    o.append("                                                        int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window, uint32_t bound) {")
+    o.append("                                                        int32_t& budget, uint32_t& acc, uint32_t thr, uint32_t window) {")
     o.append("    uint32_t leaf;")
     o.append("    float t0, t1, t2, t3, t4, t5, t6;")
     o.append("    switch (form) {")
