@@ -109,9 +109,12 @@ int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_
  * rts_bvh_build_device = PLOC with radius 16 (the better tree); rts_bvh_build_device_ex picks the topology:
  *   RTS_GPU_BUILD_LBVH  Karras hierarchy + bottom-up bounds (fastest build)
  *   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering, `radius` = Morton neighbours searched each way (0 = 16)
+ *   RTS_GPU_BUILD_PLOC_SAH  PLOC down to <= 65 536 clusters, then the top of the tree over the clusters' boxes by the
+ *                       reference's split rule (full-sweep SAH, BVHBuilder.cpp:78-156, weighted by triangle counts) on
+ *                       the host: ~10x the build time of PLOC, a tree closer to BVHBuilder's
  * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
  * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build. */
-enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1 };
+enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1, RTS_GPU_BUILD_PLOC_SAH = 2 };
 int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
                          const uint32_t* indices, uint32_t prim_count, rts_vec4u* out_packed,
                          size_t out_capacity_vec4, int install, float* build_ms);

@@ -4,6 +4,9 @@
 //   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering (Meister & Bittner 2018): every cluster looks `radius`
 //                       neighbours up and down the Morton order for the partner whose union has the smallest surface
 //                       area, mutual pairs merge, the array is compacted, repeat until one cluster is left (default)
+//   RTS_GPU_BUILD_PLOC_SAH  the same until at most 65 536 clusters are left, then the top of the tree over those clusters
+//                       by the reference's own split rule -- full-sweep SAH on all three axes, BVHBuilder.cpp:78-156,
+//                       with the clusters' triangle counts as weights -- on the host (the clusters' boxes travel, 1.8 MB)
 // then the reference's own layout rules applied to that topology:
 //   * child with the larger surface area first            (Source/BVHBuilder.cpp:202-208, strict `>` on the right one)
 //   * depth-first (pre-order) numbering, left child = i+1 (cpp:222-238)
@@ -18,7 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <algorithm>
 #include <utility>
+#include <vector>
 #include "../../include/rts.h"
 
 extern "C" int rts_ctx_adopt_device_bvh(rts_ctx* ctx, void* d_packed, size_t count_vec4, uint32_t prim_count);  // rts_api.cpp
@@ -273,6 +278,118 @@ __global__ void plocRootKernel(Lbvh b, Ploc c) {                       // the la
     if (blockIdx.x == 0 && threadIdx.x == 0) b.parent[c.id[0]] = END;
 }
 
+// ---- top of the tree over PLOC clusters (host) -------------------------------------------------------------------
+// Input: n clusters (node id, box, triangles below).  Output: n - 1 internal nodes with ids firstId .. firstId + n - 2
+// (a parent's id is lower than its children's), children ordered "larger surface area first" (cpp:202-208).
+struct TopTree {
+    std::vector<uint32_t> child, leaves, pairs;     // 2 per node; 1 per node; (child id, parent id) per link
+    std::vector<float> lo, hi;                      // 3 per node
+    uint32_t root = 0;
+};
+
+static float hostArea(const float* lo, const float* hi) {
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return (ex * ey + ey * ez + ez * ex) * 2.0f;
+}
+
+static void buildTopSah(uint32_t n, const uint32_t* id, const float* lo, const float* hi, const uint32_t* weight,
+                        uint32_t firstId, TopTree* out) {
+    const uint32_t inner = n - 1;
+    out->child.assign((size_t)inner * 2, 0); out->leaves.assign(inner, 0);
+    out->lo.assign((size_t)inner * 3, 0.f); out->hi.assign((size_t)inner * 3, 0.f);
+    std::vector<float> ctr((size_t)n * 3);
+    for (size_t i = 0; i < (size_t)n * 3; ++i) ctr[i] = (lo[i] + hi[i]) * 0.5f;
+    // three index arrays, each sorted once by the centroid on its axis (ties by position: deterministic); a split keeps
+    // them sorted by partitioning the two other arrays stably: O(n) per level instead of a sort per node
+    std::vector<uint32_t> ord[3], tmp(n);
+    for (int axis = 0; axis < 3; ++axis) {
+        ord[axis].resize(n);
+        for (uint32_t i = 0; i < n; ++i) ord[axis][i] = i;
+        std::stable_sort(ord[axis].begin(), ord[axis].end(), [&](uint32_t x, uint32_t y) { return ctr[(size_t)x * 3 + axis] < ctr[(size_t)y * 3 + axis]; });
+    }
+    std::vector<uint8_t> left(n, 0);
+    std::vector<float> saR(n);
+    std::vector<double> wR(n);
+    struct Range { uint32_t begin, end, parent, side; };           // parent = index of the new node (0-based), ~0u for the root
+    std::vector<Range> work;
+    work.push_back(Range{ 0, n, 0xFFFFFFFFu, 0 });
+    uint32_t next = 0;
+    auto link = [&](const Range& r, uint32_t ref) {
+        if (r.parent == 0xFFFFFFFFu) out->root = ref; else out->child[(size_t)r.parent * 2 + r.side] = ref;
+    };
+    while (!work.empty()) {
+        const Range r = work.back();
+        work.pop_back();
+        const uint32_t cnt = r.end - r.begin;
+        if (cnt == 1) { link(r, id[ord[0][r.begin]]); continue; }
+        float bestCost = __builtin_inff();
+        uint32_t bestMid = cnt / 2; int bestAxis = 0;              // (if every cost overflows: the median on x)
+        for (int axis = 0; axis < 3; ++axis) {
+            const uint32_t* perm = ord[axis].data() + r.begin;
+            float blo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, bhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+            double w = 0;
+            for (uint32_t k = cnt; k-- > 0;) {                   // suffix areas and weights
+                const uint32_t c = perm[k];
+                for (int a = 0; a < 3; ++a) { blo[a] = lo[(size_t)c * 3 + a] < blo[a] ? lo[(size_t)c * 3 + a] : blo[a]; bhi[a] = hi[(size_t)c * 3 + a] > bhi[a] ? hi[(size_t)c * 3 + a] : bhi[a]; }
+                w += weight[c];
+                saR[k] = hostArea(blo, bhi); wR[k] = w;
+            }
+            for (int a = 0; a < 3; ++a) { blo[a] = __builtin_inff(); bhi[a] = -__builtin_inff(); }
+            w = 0;
+            for (uint32_t k = 0; k + 1 < cnt; ++k) {             // prefix sweep: split after position k
+                const uint32_t c = perm[k];
+                for (int a = 0; a < 3; ++a) { blo[a] = lo[(size_t)c * 3 + a] < blo[a] ? lo[(size_t)c * 3 + a] : blo[a]; bhi[a] = hi[(size_t)c * 3 + a] > bhi[a] ? hi[(size_t)c * 3 + a] : bhi[a]; }
+                w += weight[c];
+                const float cost = (float)(hostArea(blo, bhi) * w + saR[k + 1] * wR[k + 1]);
+                if (cost < bestCost) { bestCost = cost; bestMid = k + 1; bestAxis = axis; }
+            }
+        }
+        for (uint32_t k = 0; k < cnt; ++k) left[ord[bestAxis][r.begin + k]] = k < bestMid ? 1 : 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            if (axis == bestAxis) continue;
+            uint32_t* perm = ord[axis].data() + r.begin;
+            uint32_t nl = 0, nr = 0;
+            for (uint32_t k = 0; k < cnt; ++k) { if (left[perm[k]]) perm[nl++] = perm[k]; else tmp[nr++] = perm[k]; }
+            std::copy(tmp.begin(), tmp.begin() + nr, perm + nl);
+        }
+        const uint32_t node = next++;
+        link(r, firstId + node);
+        work.push_back(Range{ r.begin + bestMid, r.end, node, 1 });
+        work.push_back(Range{ r.begin, r.begin + bestMid, node, 0 });
+    }
+    // boxes, counts, child order: children have higher ids than their parent, so walk the new nodes from the last to the first
+    std::vector<float> clo((size_t)n * 3), chi((size_t)n * 3);
+    auto boxOf = [&](uint32_t ref, const float** l, const float** h, uint32_t* cntOut, const std::vector<uint32_t>& where) {
+        if (ref >= firstId && ref < firstId + inner) { const uint32_t k = ref - firstId; *l = &out->lo[(size_t)k * 3]; *h = &out->hi[(size_t)k * 3]; *cntOut = out->leaves[k]; }
+        else { const uint32_t c = where[ref]; *l = &lo[(size_t)c * 3]; *h = &hi[(size_t)c * 3]; *cntOut = weight[c]; }
+    };
+    (void)clo; (void)chi;
+    std::vector<uint32_t> where;                                   // node id -> cluster position
+    {
+        uint32_t maxId = 0;
+        for (uint32_t i = 0; i < n; ++i) maxId = id[i] > maxId ? id[i] : maxId;
+        where.assign((size_t)maxId + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) where[id[i]] = i;
+    }
+    out->pairs.clear();
+    for (uint32_t k = inner; k-- > 0;) {
+        uint32_t* ch = &out->child[(size_t)k * 2];
+        const float *l0, *h0, *l1, *h1; uint32_t c0, c1;
+        boxOf(ch[0], &l0, &h0, &c0, where); boxOf(ch[1], &l1, &h1, &c1, where);
+        for (int a = 0; a < 3; ++a) { out->lo[(size_t)k * 3 + a] = l0[a] < l1[a] ? l0[a] : l1[a]; out->hi[(size_t)k * 3 + a] = h0[a] > h1[a] ? h0[a] : h1[a]; }
+        out->leaves[k] = c0 + c1;
+        if (hostArea(l1, h1) > hostArea(l0, h0)) std::swap(ch[0], ch[1]);       // larger child first (cpp:202-208)
+        out->pairs.push_back(ch[0]); out->pairs.push_back(firstId + k);
+        out->pairs.push_back(ch[1]); out->pairs.push_back(firstId + k);
+    }
+}
+
+__global__ void setParentsKernel(Lbvh b, const uint32_t* pairs, uint32_t nPairs, uint32_t root) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nPairs) b.parent[pairs[2 * i]] = pairs[2 * i + 1];
+    if (i == 0) b.parent[root] = END;
+}
+
 // Pre-order index of a node = sum over its ancestors of (1 + size of the sibling subtree visited before it).
 __global__ void emitKernel(Lbvh b, const uint32_t* order, uint32_t* packed) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,7 +463,8 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
                                        const uint32_t* indices, uint32_t P, int algorithm, uint32_t radius,
                                        rts_vec4u* out_packed, size_t out_cap, int install, float* build_ms) {
     if (!ctx || !vertices || !indices || P == 0 || stride < 3 || P > 0x0CCCCCCCu) return RTS_ERR_INVALID_ARG;
-    if ((algorithm != RTS_GPU_BUILD_LBVH && algorithm != RTS_GPU_BUILD_PLOC) || radius > 256) return RTS_ERR_INVALID_ARG;
+    if ((algorithm != RTS_GPU_BUILD_LBVH && algorithm != RTS_GPU_BUILD_PLOC && algorithm != RTS_GPU_BUILD_PLOC_SAH) || radius > 256)
+        return RTS_ERR_INVALID_ARG;
     if (radius == 0) radius = 16;
     const size_t count = (size_t)5 * P - 2;
     if (out_packed && out_cap < count) return RTS_ERR_CAPACITY;
@@ -401,7 +519,8 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         LB_HIP(arena.get(&temp, tempBytes));
         LB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, b.keys, keysAlt, b.order, orderAlt, (int)P, 0, 63, nullptr));
         sortedKeys = keysAlt; sortedOrder = orderAlt;
-        if (algorithm == RTS_GPU_BUILD_PLOC) {
+        if (algorithm == RTS_GPU_BUILD_PLOC || algorithm == RTS_GPU_BUILD_PLOC_SAH) {
+            const uint32_t stopAt = algorithm == RTS_GPU_BUILD_PLOC_SAH ? 65536u : 1u;
             Ploc c{};
             c.n = P; c.radius = radius;
             LB_HIP(arena.get(&c.id, (size_t)P * 4)); LB_HIP(arena.get(&c.idOut, (size_t)P * 4));
@@ -415,7 +534,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             void* scanTemp;
             LB_HIP(arena.get(&scanTemp, scanBytes));
             hipLaunchKernelGGL(plocInitKernel, gridP, block, 0, nullptr, b, c, sortedOrder);
-            for (uint32_t round = 0; c.n > 1; ++round) {
+            for (uint32_t round = 0; c.n > stopAt; ++round) {
                 if (round > 4u * 1024u * 1024u) { arena.release(); return RTS_ERR_BAD_BVH; }      // (every round merges at least one pair)
                 const dim3 grid((c.n + 255) / 256);
                 hipLaunchKernelGGL(plocNearestKernel, grid, block, 0, nullptr, c);
@@ -430,7 +549,37 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
                 c.n = next;
                 std::swap(c.id, c.idOut); std::swap(c.lo, c.loOut); std::swap(c.hi, c.hiOut);
             }
-            hipLaunchKernelGGL(plocRootKernel, dim3(1), dim3(64), 0, nullptr, b, c);
+            if (c.n == 1) {
+                hipLaunchKernelGGL(plocRootKernel, dim3(1), dim3(64), 0, nullptr, b, c);
+            } else {
+                // the top of the tree over the remaining clusters: full-sweep SAH on the host
+                try {
+                    const uint32_t n = c.n;
+                    std::vector<uint32_t> ids(n), allLeaves(P), weight(n);
+                    std::vector<float> lo((size_t)n * 3), hi((size_t)n * 3);
+                    uint32_t firstId = 0;
+                    LB_HIP(hipMemcpy(ids.data(), c.id, (size_t)n * 4, hipMemcpyDeviceToHost));
+                    LB_HIP(hipMemcpy(lo.data(), c.lo, (size_t)n * 12, hipMemcpyDeviceToHost));
+                    LB_HIP(hipMemcpy(hi.data(), c.hi, (size_t)n * 12, hipMemcpyDeviceToHost));
+                    LB_HIP(hipMemcpy(allLeaves.data(), b.leaves, (size_t)(P - 1) * 4, hipMemcpyDeviceToHost));
+                    LB_HIP(hipMemcpy(&firstId, c.nextId, 4, hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < n; ++i) weight[i] = ids[i] >= P - 1 ? 1u : allLeaves[ids[i]];
+                    TopTree top;
+                    buildTopSah(n, ids.data(), lo.data(), hi.data(), weight.data(), firstId, &top);
+                    uint32_t* d_pairs;
+                    LB_HIP(arena.get(&d_pairs, top.pairs.size() * 4));
+                    LB_HIP(hipMemcpy(d_pairs, top.pairs.data(), top.pairs.size() * 4, hipMemcpyHostToDevice));
+                    LB_HIP(hipMemcpy(b.child + (size_t)firstId * 2, top.child.data(), top.child.size() * 4, hipMemcpyHostToDevice));
+                    LB_HIP(hipMemcpy(b.leaves + firstId, top.leaves.data(), top.leaves.size() * 4, hipMemcpyHostToDevice));
+                    LB_HIP(hipMemcpy(b.nodeLo + (size_t)firstId * 3, top.lo.data(), top.lo.size() * 4, hipMemcpyHostToDevice));
+                    LB_HIP(hipMemcpy(b.nodeHi + (size_t)firstId * 3, top.hi.data(), top.hi.size() * 4, hipMemcpyHostToDevice));
+                    const uint32_t nPairs = (uint32_t)(top.pairs.size() / 2);
+                    hipLaunchKernelGGL(setParentsKernel, dim3((nPairs + 255) / 256), block, 0, nullptr, b, d_pairs, nPairs, top.root);
+                } catch (...) {
+                    arena.release();
+                    return RTS_ERR_CAPACITY;
+                }
+            }
         } else {
             hipLaunchKernelGGL(hierarchyKernel, gridP, block, 0, nullptr, b, sortedKeys);
             // bottom-up bounds: repeated sweeps, each finalising the nodes whose children were final before it

@@ -18,7 +18,7 @@ def main():
             api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, want_packed=False)   # warm-up (hipcub, allocs)
             base = None
             for name, algo, radius in (("SAH (host build)", None, 0), ("LBVH", "lbvh", 0), ("PLOC r=8", "ploc", 8), ("PLOC r=16", "ploc", 16),
-                                       ("PLOC r=32", "ploc", 32)):
+                                       ("PLOC r=32", "ploc", 32), ("PLOC r=16 + SAH top", "ploc_sah", 16)):
                 if algo is None:
                     ctx.set_bvh(wl.packed)
                     ref, ms, wall = wl.packed, wl.build_seconds * 1e3, wl.build_seconds * 1e3
