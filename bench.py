@@ -172,6 +172,55 @@ def committed_counters(kname, config, say):
     return None
 
 
+def roofline_bounds(counters, avg_launch_s, clock_mhz):
+    """The two measured bounds of the module docstring from one set of per-launch counters (live passes or the committed
+    fallback), the launch time of this run and the shader clock measured in this run.  Pure arithmetic: tested on the CPU
+    against the committed counters (tests/test_host_logic.py)."""
+    roof = {}
+    hbm = issue = None
+    if counters:
+        c, cal = counters["counters_per_launch"], counters.get("calibration_counters_per_launch", {})
+        known = counters.get("calibration", {})
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            # gfx950: FETCH_SIZE reads 1/2 of a wide (16 B/lane) stream (MI355X_MICROARCH.md, HBM); calibrated in the same
+            # pass against the frame whose read volume is known rather than assumed
+            factor = known["known_read_bytes"] / (cal["FETCH_SIZE"] * 1024) if cal.get("FETCH_SIZE") else 2.0
+            fetch = c["FETCH_SIZE"] * 1024 * factor
+            write = c["WRITE_SIZE"] * 1024                       # exact for streaming stores; byte stores count 32-B sectors
+            traffic = fetch + write
+            hbm = {"bytes_per_launch": int(traffic), "fetch_bytes": int(fetch), "write_bytes": int(write),
+                   "fetch_factor_calibrated": round(factor, 4),
+                   "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+            if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+                hbm["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        if "SQ_INSTS_VALU" in c and clock_mhz:
+            per = c["SQ_INSTS_VALU"] / (avg_launch_s * clock_mhz * 1e6 * SIMDS)
+            issue = {"valu_instr_per_launch": int(c["SQ_INSTS_VALU"]), "achieved": round(per, 4),
+                     "peak": VALU_PEAK_PER_CLK_SIMD, "unit": "wave64 VALU instr / clk / SIMD",
+                     "frac": round(per / VALU_PEAK_PER_CLK_SIMD, 4)}
+            for k in ("SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES"):
+                if k in c:
+                    issue[k.lower()] = int(c[k])
+            if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+                issue["wait_any_share_of_wave_cycles"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+        roof["counters_source"] = counters.get("source")
+        roof["source_hash"] = source_hash()
+        if "kernel_trace" in counters:
+            roof["profiler_avg_launch_ms"] = round(counters["kernel_trace"]["avg_ns"] / 1e6, 5)
+            roof["kernel_trace"] = counters["kernel_trace"]
+    pick = max([b for b in (("hbm", hbm), ("valu_issue", issue)) if b[1]], key=lambda b: b[1]["frac"], default=None)
+    if pick:
+        roof.update({"bound": pick[0], "achieved": pick[1]["achieved"], "peak": pick[1]["peak"], "unit": pick[1]["unit"],
+                     "frac": pick[1]["frac"]})
+    else:
+        roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+    roof["traffic"] = hbm["bytes_per_launch"] if hbm else None
+    roof["hbm"] = hbm
+    roof["valu_issue"] = issue
+    return roof
+
+
 def pmc_child(args):
     """The command the profiler passes run: a few launches on the calibration frame (1-triangle BVH: the read volume is
     the position stream, known), then on the real one.  Prints a one-line manifest."""
@@ -440,47 +489,7 @@ def main():
             json.dump(rec, fh, indent=1)
     if N == 1 and counters is None and not args.no_pmc:
         counters = committed_counters(kname, args.config, say)
-    hbm = issue = None
-    if counters:
-        c, cal = counters["counters_per_launch"], counters.get("calibration_counters_per_launch", {})
-        known = counters.get("calibration", {})
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            # gfx950: FETCH_SIZE reads 1/2 of a wide (16 B/lane) stream (MI355X_MICROARCH.md, HBM); calibrated in the same
-            # pass against the frame whose read volume is known rather than assumed
-            factor = known["known_read_bytes"] / (cal["FETCH_SIZE"] * 1024) if cal.get("FETCH_SIZE") else 2.0
-            fetch = c["FETCH_SIZE"] * 1024 * factor
-            write = c["WRITE_SIZE"] * 1024                       # exact for streaming stores; byte stores count 32-B sectors
-            traffic = fetch + write
-            hbm = {"bytes_per_launch": int(traffic), "fetch_bytes": int(fetch), "write_bytes": int(write),
-                   "fetch_factor_calibrated": round(factor, 4),
-                   "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-            hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
-            if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
-                hbm["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
-        if "SQ_INSTS_VALU" in c and clock_mhz:
-            per = c["SQ_INSTS_VALU"] / (avg_launch_s * clock_mhz * 1e6 * SIMDS)
-            issue = {"valu_instr_per_launch": int(c["SQ_INSTS_VALU"]), "achieved": round(per, 4),
-                     "peak": VALU_PEAK_PER_CLK_SIMD, "unit": "wave64 VALU instr / clk / SIMD",
-                     "frac": round(per / VALU_PEAK_PER_CLK_SIMD, 4)}
-            for k in ("SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES"):
-                if k in c:
-                    issue[k.lower()] = int(c[k])
-            if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
-                issue["wait_any_share_of_wave_cycles"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
-        roof["counters_source"] = counters.get("source")
-        roof["source_hash"] = source_hash()
-        if "kernel_trace" in counters:
-            roof["profiler_avg_launch_ms"] = round(counters["kernel_trace"]["avg_ns"] / 1e6, 5)
-            roof["kernel_trace"] = counters["kernel_trace"]
-    pick = max([b for b in (("hbm", hbm), ("valu_issue", issue)) if b[1]], key=lambda b: b[1]["frac"], default=None)
-    if pick:
-        roof.update({"bound": pick[0], "achieved": pick[1]["achieved"], "peak": pick[1]["peak"], "unit": pick[1]["unit"],
-                     "frac": pick[1]["frac"]})
-    else:
-        roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
-    roof["traffic"] = hbm["bytes_per_launch"] if hbm else None
-    roof["hbm"] = hbm
-    roof["valu_issue"] = issue
+    roof.update(roofline_bounds(counters, avg_launch_s, clock_mhz))
     result["roofline"] = roof
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on the host cores, same frame ---------------

@@ -119,3 +119,27 @@ def test_committed_counter_summary_belongs_to_this_kernel_build():
     assert rec is not None, "profiles/**/counters_city_4k.json is missing or belongs to another kernel build: re-run tools/final_evidence.sh"
     c = rec["counters_per_launch"]
     assert c["SQ_WAVES"] == 129600 and 1.0e8 < c["SQ_INSTS_VALU"] < 2.0e8 and c["FETCH_SIZE"] > 0 and c["WRITE_SIZE"] > 0
+
+
+def test_roofline_arithmetic_on_the_committed_counters():
+    """bench.py's two bounds recomputed on the CPU from profiles/r02/counters_city_4k.json: fractions of a bound, never above
+    1 for any plausible launch time, the larger one named, `traffic` = calibrated fetch + raw write bytes."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = bench.committed_counters("shadowMaskPacketKernel<1>", "city_4k", lambda *a: None)
+    roof = bench.roofline_bounds(rec, 0.1705e-3, 2300.0)
+    assert roof["bound"] == "valu_issue" and 0.5 < roof["frac"] < 0.8 and roof["unit"].startswith("wave64 VALU")
+    assert 0.10 < roof["hbm"]["frac"] < 0.20 and abs(roof["hbm"]["fetch_factor_calibrated"] - 2.0) < 0.01
+    assert roof["traffic"] == roof["hbm"]["fetch_bytes"] + roof["hbm"]["write_bytes"] > 150e6
+    assert roof["valu_issue"]["frac"] == roof["frac"] and roof["valu_issue"]["sq_waves"] == 129600
+    for t in (0.12e-3, 0.17e-3, 0.3e-3):                                   # no launch time this kernel can reach exceeds a bound
+        r = bench.roofline_bounds(rec, t, 2400.0)
+        assert r["frac"] <= 1.0 and r["hbm"]["frac"] <= 1.0
+    none = bench.roofline_bounds(None, 0.17e-3, 2400.0)
+    assert none["frac"] is None and none["traffic"] is None and none["bound"] == "hbm"
+    no_clock = bench.roofline_bounds(rec, 0.17e-3, None)                   # without a measured clock only the HBM bound is claimed
+    assert no_clock["bound"] == "hbm" and no_clock["valu_issue"] is None
