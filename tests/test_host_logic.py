@@ -134,7 +134,7 @@ def test_roofline_arithmetic_on_the_committed_counters():
     roof = bench.roofline_bounds(rec, 0.1705e-3, 2300.0)
     assert roof["bound"] == "valu_issue" and 0.5 < roof["frac"] < 0.8 and roof["unit"].startswith("wave64 VALU")
     assert 0.10 < roof["hbm"]["frac"] < 0.20 and abs(roof["hbm"]["fetch_factor_calibrated"] - 2.0) < 0.01
-    assert roof["traffic"] == roof["hbm"]["fetch_bytes"] + roof["hbm"]["write_bytes"] > 150e6
+    assert abs(roof["traffic"] - (roof["hbm"]["fetch_bytes"] + roof["hbm"]["write_bytes"])) <= 2 and roof["traffic"] > 150e6
     assert roof["valu_issue"]["frac"] == roof["frac"] and roof["valu_issue"]["sq_waves"] == 129600
     for t in (0.12e-3, 0.17e-3, 0.3e-3):                                   # no launch time this kernel can reach exceeds a bound
         r = bench.roofline_bounds(rec, t, 2400.0)
