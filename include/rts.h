@@ -170,7 +170,8 @@ int rts_trace_shadow_mask_device(rts_ctx* ctx, const rts_constants* constants, c
                                  uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, void* stream);
 
 /* Interleaved row stripes in ONE dispatch (multi-GPU strong scaling): the frame is cut
- * into bands of band_rows rows (a multiple of 32) dealt round-robin to n_stripes devices; this call
+ * into bands of band_rows rows (a multiple of the kernel's workgroup height: 8 for the default packet kernel, 16 or 32 for
+ * the others -- 32 always works) dealt round-robin to n_stripes devices; this call
  * traces the bands stripe, stripe + n_stripes, ... and touches no other row of d_mask. */
 int rts_trace_shadow_mask_stripes_device(rts_ctx* ctx, const rts_constants* constants, const rts_light* light,
                                          const float* d_positions, uint32_t W, uint32_t H, uint32_t band_rows,

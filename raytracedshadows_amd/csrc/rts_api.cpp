@@ -254,6 +254,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_SHARE;
     uint32_t bw, bh;
     rts::tileShape(variant, c->blockWaves, &bw, &bh);
+    if (n_stripes > 1 && band_rows % bh != 0) return RTS_ERR_INVALID_ARG;   // a band is a whole number of workgroup rows (8, 16 or 32 pixel rows)
     p.blocksX = (W + bw - 1) / bw;
     p.blocksY = (rows + bh - 1) / bh;
     p.nBlocks = p.blocksX * p.blocksY;
@@ -291,7 +292,7 @@ int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_l
 int rts_trace_shadow_mask_stripes_device(rts_ctx* c, const rts_constants* k, const rts_light* light,
                                          const float* d_positions, uint32_t W, uint32_t H, uint32_t band_rows,
                                          uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, void* stream) {
-    if (band_rows == 0 || band_rows % 32 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
+    if (band_rows == 0 || band_rows % 8 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
     if (n_stripes == 1) return traceMaskImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, stream);
     // rows this stripe owns: whole bands stripe, stripe+n, ... (the last one may be cut by H)
     const uint32_t bands = (H + band_rows - 1) / band_rows;

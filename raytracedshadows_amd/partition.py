@@ -6,7 +6,7 @@ def stripe_rows(height, n_ranks, rank, band=32, interleaved=True):
 
     interleaved: bands of `band` rows dealt round-robin (balances sky vs geometry);
     otherwise one contiguous block of rows per rank, rounded to `band`.  The default band (32) is what
-    rts_trace_shadow_mask_stripes_device accepts (a multiple of 32 rows).
+    rts_trace_shadow_mask_stripes_device accepts for every kernel (the default packet kernel also takes multiples of 8).
     """
     if n_ranks < 1 or not 0 <= rank < n_ranks or band < 1:
         raise ValueError("bad stripe arguments")

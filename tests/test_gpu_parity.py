@@ -531,9 +531,21 @@ def test_interleaved_stripes_single_dispatch(ctx):
                 own[b:e] = True
             assert (got[own] == want[own]).all() and (got[~own] == 7).all()
         with pytest.raises(api.RtsError):
-            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 24, 2, 0)      # band not a multiple of 32
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 20, 2, 0)      # band not a multiple of 8
         with pytest.raises(api.RtsError):
             ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 2, 2)      # stripe out of range
+        ctx.set_option("kernel", 5)
+        with pytest.raises(api.RtsError):
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 8, 2, 0)       # 16x16 tiles x 2x2 per workgroup need 32-row bands
+        ctx.set_option("kernel", 3)                          # the default packet kernel (one 8x8 tile per workgroup) takes 8-row bands
+        for n in (2, 5):
+            got = np.full((H, W), 7, np.uint8)
+            ctx.h2d(d_mask, got)
+            for stripe in range(n):
+                ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 8, n, stripe, light=wl.light)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            assert (got == want).all(), ("band 8", n)
     finally:
         ctx.set_option("kernel", -1)
         ctx.free(d_pos)

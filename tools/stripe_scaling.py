@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="city_4k")
+    ap.add_argument("--band", type=int, default=32)
     args = ap.parse_args()
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config, cache=True)
@@ -28,7 +29,7 @@ def main():
             worst, times = 0.0, []
             for r in range(n):
                 def go():
-                    ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, r, light=wl.light)
+                    ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, args.band, n, r, light=wl.light)
                 for _ in range(300):
                     go()
                 ts = []
@@ -38,7 +39,7 @@ def main():
                 times.append(float(np.median(ts)))
             worst = max(times)
             base = base or worst
-            print(f"[{args.config}] {n} stripe(s): per-stripe ms {' '.join(f'{t:.4f}' for t in times)}; slowest {worst:.4f} ms "
+            print(f"[{args.config}] band {args.band}, {n} stripe(s): per-stripe ms {' '.join(f'{t:.4f}' for t in times)}; slowest {worst:.4f} ms "
                   f"-> {wl.rays / worst / 1e6:.1f} Grays/s aggregate, predicted efficiency {base / (n * worst) * 100:.0f} % ({ctx.last_kernel_name()})",
                   flush=True)
         ctx.free(d_pos)
