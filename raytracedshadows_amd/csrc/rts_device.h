@@ -42,7 +42,6 @@ struct TraceParams {
     const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
     uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
-    uint32_t samplePairs;     // soft shadows: two samples of a pixel per lane share one walk (experiment)
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
     float offsets[64][4];

@@ -718,37 +718,6 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
 }
 
-// Soft shadows, two samples per pass: the rays of one pixel towards two neighbouring light samples walk almost the same
-// nodes, so a lane carries both (the K = 2 packet machinery: one node fetch and one set of scalar bookkeeping per step for
-// 128 rays).  Plain launches only (2-D grid, natural order, one contiguous row range).
-template <int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
-void shadowMaskSamplePairKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[1][64];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t x = blockIdx.x * 8u + (lane & 7u);
-    const uint32_t y = p.rowBegin + dispatchRow(p, blockIdx.y) * 8u + (lane >> 3);
-    const bool live0 = (x < p.W) && (y < p.rowEnd);
-    const size_t pix = (size_t)y * p.W + x;
-    F3 rel{ 0.f, 0.f, 0.f };
-    if (live0) {
-        f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix);               // comp:135
-        rel = F3{ t.x, t.y, t.z };
-    }
-    const NodeStream bvh = openStream(p);
-    const uint32_t ns = p.nsamples;
-    uint32_t lit = 0;
-    for (uint32_t s = 0; s < ns; s += 2u) {
-        const uint32_t s1 = s + 1u < ns ? s + 1u : s;
-        const Ray r[2] = { makeShadowRay(p, rel, s), makeShadowRay(p, rel, s1) };
-        const bool ll[2] = { live0, live0 && s + 1u < ns };
-        bool occluded[2];
-        traversePacket<2, false>(p, bvh, r, ll, occluded, shareSlots[0]);
-        lit += (occluded[0] ? 0u : 1u) + ((ll[1] && !occluded[1]) ? 1u : 0u);                // comp:148
-    }
-    if (live0) __builtin_nontemporal_store((uint8_t)lit, &p.mask[pix]);                      // comp:150
-}
-
 template <int VARIANT>
 __global__ __launch_bounds__(256) void traceRaysKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[4][64];
@@ -813,11 +782,7 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         dim3 b1(64);
         switch (variant) {
         case V_PACKET:
-            if (soft && p.samplePairs && p.grid2d && p.nStripes <= 1 && !p.waveStats) {
-                if (p.samplePairs == 8) hipLaunchKernelGGL(shadowMaskSamplePairKernel<8>, grid, b1, ldsPad, stream, p);
-                else if (p.samplePairs == 6) hipLaunchKernelGGL(shadowMaskSamplePairKernel<6>, grid, b1, ldsPad, stream, p);
-                else hipLaunchKernelGGL(shadowMaskSamplePairKernel<4>, grid, b1, ldsPad, stream, p);
-            } else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
+            if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
             else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);
