@@ -103,18 +103,23 @@ int rts_bvh_build_ex(const float* vertices, uint32_t stride_floats, const uint32
  * count == 5P-2, leaf/inner tags, strictly-forward miss links, tail pointers in range. */
 int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_count_out);
 
-/* BVH build ON THE GPU: a topology over the Morton order of the triangles, then the reference's
- * layout rules (larger-area child first, DFS numbering, miss links, tail; BVHBuilder.cpp:202-244, 308-367).  The tree is
- * NOT BVHBuilder's SAH tree (use rts_bvh_build for that); it is another valid producer of the same packed layout.
- * rts_bvh_build_device = PLOC with radius 16 (the better tree); rts_bvh_build_device_ex picks the topology:
+/* BVH build ON THE GPU: four producers of the same packed layout with the reference's layout rules
+ * (larger-area child first, DFS numbering, miss links, tail; BVHBuilder.cpp:202-244, 308-367).
+ * rts_bvh_build_device = RTS_GPU_BUILD_SAH (BVHBuilder's tree); rts_bvh_build_device_ex picks the topology:
  *   RTS_GPU_BUILD_LBVH  Karras hierarchy + bottom-up bounds (fastest build)
  *   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering, `radius` = Morton neighbours searched each way (0 = 16)
  *   RTS_GPU_BUILD_PLOC_SAH  PLOC down to <= 65 536 clusters, then the top of the tree over the clusters' boxes by the
  *                       reference's split rule (full-sweep SAH, BVHBuilder.cpp:78-156, weighted by triangle counts) on
  *                       the host: ~10x the build time of PLOC, a tree closer to BVHBuilder's
+ *   RTS_GPU_BUILD_SAH   BVHBuilder's own rule for every node, level by level on the device: full-sweep SAH on three
+ *                       axes (cpp:78-156), spatial median above `radius` triangles per range (cpp:157-178; 0 = the
+ *                       reference's 1 000 000), larger-area child first.  Triangles with EQUAL centroids on an axis are
+ *                       ordered by triangle id where the reference's std::sort leaves them unspecified: on a mesh
+ *                       without such ties the stream is byte-identical to rts_bvh_build's, otherwise a tree of the
+ *                       same quality.  RTS_ERR_DEGENERATE where the reference would not terminate.
  * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
  * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build. */
-enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1, RTS_GPU_BUILD_PLOC_SAH = 2 };
+enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1, RTS_GPU_BUILD_PLOC_SAH = 2, RTS_GPU_BUILD_SAH = 3 };
 int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
                          const uint32_t* indices, uint32_t prim_count, rts_vec4u* out_packed,
                          size_t out_capacity_vec4, int install, float* build_ms);

@@ -99,15 +99,25 @@ static OBox rangeBounds(const std::vector<ONode>& n, u32 begin, u32 end) {
 }
 
 // BVHBuilder.cpp:78-179
-static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nodeBounds, u32 sahLimit) {
+// tieByPrim (not in the reference): equal centroids are ordered by triangle id instead of being left wherever
+// std::sort puts them -- the deterministic variant the GPU SAH builder (RTS_GPU_BUILD_SAH) is specified by.  On input
+// without equal centroids both rules give the same tree.
+struct CtrLess {
+    u32 axis; bool tieByPrim;
+    bool operator()(const ONode& a, const ONode& b) const {
+        if (a.ctr[axis] < b.ctr[axis]) return true;
+        return tieByPrim && a.ctr[axis] == b.ctr[axis] && a.prim < b.prim;
+    }
+};
+
+static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nodeBounds, u32 sahLimit, bool tieByPrim = false) {
     const u32 count = end - begin;
     u32 bestSplit = begin;                                    // cpp:81 (carried across axes)
     if (count <= sahLimit) {                                  // cpp:83 (1000000 in the reference)
         u32 bestAxis = 0, globalBestSplit = begin;
         float globalBestCost = FLT_MAX;
         for (u32 axis = 0; axis < 3; ++axis) {
-            std::sort(n.begin() + begin, n.begin() + end,     // cpp:92-96
-                      [axis](const ONode& a, const ONode& b) { return a.ctr[axis] < b.ctr[axis]; });
+            std::sort(n.begin() + begin, n.begin() + end, CtrLess{ axis, tieByPrim });     // cpp:92-96
             OBox bl, br; boxInit(bl); boxInit(br);
             for (u32 il = 0; il < count; ++il) {              // cpp:104-119
                 u32 ir = count - il - 1;
@@ -127,8 +137,7 @@ static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nod
                 globalBestSplit = bestSplit; globalBestCost = bestCost; bestAxis = axis;
             }
         }
-        std::sort(n.begin() + begin, n.begin() + end,         // cpp:149-153
-                  [bestAxis](const ONode& a, const ONode& b) { return a.ctr[bestAxis] < b.ctr[bestAxis]; });
+        std::sort(n.begin() + begin, n.begin() + end, CtrLess{ bestAxis, tieByPrim });     // cpp:149-153
         return globalBestSplit;
     }
     // cpp:157-178: spatial median on the widest axis (first maximum wins, std::max_element)
@@ -136,8 +145,7 @@ static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nod
                      nodeBounds.hi[2] - nodeBounds.lo[2] };
     int major = 0;
     for (int k = 1; k < 3; ++k) if (ext[major] < ext[k]) major = k;
-    std::sort(n.begin() + begin, n.begin() + end,
-              [major](const ONode& a, const ONode& b) { return a.ctr[major] < b.ctr[major]; });
+    std::sort(n.begin() + begin, n.begin() + end, CtrLess{ (u32)major, tieByPrim });
     float splitPos = (nodeBounds.lo[major] + nodeBounds.hi[major]) * 0.5f;
     for (u32 mid = begin + 1; mid < end; ++mid)
         if (n[mid].ctr[major] >= splitPos) return mid;
@@ -145,16 +153,16 @@ static u32 splitRange(std::vector<ONode>& n, u32 begin, u32 end, const OBox& nod
 }
 
 // BVHBuilder.cpp:181-220
-static u32 buildRange(std::vector<ONode>& n, u32 begin, u32 end, u32 sahLimit) {
+static u32 buildRange(std::vector<ONode>& n, u32 begin, u32 end, u32 sahLimit, bool tieByPrim = false) {
     if (end - begin == 1) return begin;
     OBox bounds = rangeBounds(n, begin, end);
-    u32 mid = splitRange(n, begin, end, bounds, sahLimit);
+    u32 mid = splitRange(n, begin, end, bounds, sahLimit, tieByPrim);
     u32 id = (u32)n.size();
     n.push_back(ONode());
     ONode node; memset(&node, 0, sizeof(node));
     node.order = kInvalid; node.parent = kInvalid; node.next = kInvalid;
-    node.left = buildRange(n, begin, mid, sahLimit);
-    node.right = buildRange(n, mid, end, sahLimit);
+    node.left = buildRange(n, begin, mid, sahLimit, tieByPrim);
+    node.right = buildRange(n, mid, end, sahLimit, tieByPrim);
     float saLeft = surfaceArea(n[node.left].lo, n[node.left].hi);
     float saRight = surfaceArea(n[node.right].lo, n[node.right].hi);
     if (saRight > saLeft) std::swap(node.left, node.right);   // cpp:205-208
@@ -291,8 +299,8 @@ uint64_t orc_packed_count(uint32_t P) { return P ? 5ull * P - 2 : 0; }
 // 8*N u32 = m_nodes (BVHNode, 32 B each).  Tail .w words are written as 0 (reference: stack
 // garbage).  sah_limit = 1000000 reproduces cpp:83; tests may lower it to reach
 // the median-split branch on small inputs.  Returns 0, or -1 on P==0.
-int orc_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
-                  uint32_t sah_limit, uint32_t* out_packed, uint32_t* out_nodes) {
+static int buildPacked(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                       uint32_t sah_limit, uint32_t* out_packed, uint32_t* out_nodes, bool tieByPrim) {
     if (P == 0) return -1;
     std::vector<ONode> n;
     n.reserve((size_t)P * 2 - 1);
@@ -308,7 +316,7 @@ int orc_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indice
         node.left = kInvalid; node.right = kInvalid;
         n.push_back(node);
     }
-    u32 root = buildRange(n, 0, P, sah_limit);                 // cpp:286
+    u32 root = buildRange(n, 0, P, sah_limit, tieByPrim);      // cpp:286
     u32 order = 0;
     dfsOrder(n, root, kInvalid, order);                        // cpp:288
     const u32 N = (u32)n.size();
@@ -346,6 +354,17 @@ int orc_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indice
         out += 4;
     }
     return 0;
+}
+
+int orc_bvh_build(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                  uint32_t sah_limit, uint32_t* out_packed, uint32_t* out_nodes) {
+    return buildPacked(vertices, stride, indices, P, sah_limit, out_packed, out_nodes, false);
+}
+
+// The same builder with equal centroids ordered by triangle id (CtrLess above): what RTS_GPU_BUILD_SAH must produce.
+int orc_bvh_build_ties_by_prim(const float* vertices, uint32_t stride, const uint32_t* indices, uint32_t P,
+                               uint32_t sah_limit, uint32_t* out_packed, uint32_t* out_nodes) {
+    return buildPacked(vertices, stride, indices, P, sah_limit, out_packed, out_nodes, true);
 }
 
 // One generic ray {o.xyz, tmax} {d.xyz, 0} (the shader's `Ray`, comp:28-32).  Returns 1 on hit.

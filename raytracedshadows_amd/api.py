@@ -219,17 +219,19 @@ class BVHBuilder:
         return self
 
 
-def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, want_packed=True, algorithm="ploc",
-                     radius=16):
-    """BVH build on the GPU ("ploc": locally-ordered clustering, default; "lbvh": Karras hierarchy; "ploc_sah": PLOC below
-    65 536 clusters, full-sweep SAH over the clusters on the host above).
+def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, want_packed=True, algorithm="sah",
+                     radius=0):
+    """BVH build on the GPU.  "sah" (default): BVHBuilder's own split rule for every node, level by level on the device
+    -- ``radius`` is then the range size above which the median split is used, 0 = the reference's 1 000 000.  Over the
+    Morton order: "ploc" (locally-ordered clustering, ``radius`` neighbours each way, 0 = 16), "lbvh" (Karras hierarchy),
+    "ploc_sah" (PLOC below 65 536 clusters, full-sweep SAH over the clusters on the host above).
     Returns (packed or None, device milliseconds)."""
     vertices = np.ascontiguousarray(vertices, dtype=np.float32)
     indices = np.ascontiguousarray(indices, dtype=np.uint32)
     n = packed_count(prim_count)
     packed = np.zeros((max(n, 1), 4), dtype=np.uint32) if want_packed else None
     ms = C.c_float(0)
-    algo = {"lbvh": 0, "ploc": 1, "ploc_sah": 2}[algorithm]
+    algo = {"lbvh": 0, "ploc": 1, "ploc_sah": 2, "sah": 3}[algorithm]
     _check(_lib.rts_bvh_build_device_ex(ctx.handle, _ptr(vertices), vertices.size, stride, _ptr(indices), prim_count,
                                         algo, radius, _ptr(packed) if want_packed else None, n if want_packed else 0,
                                         int(install), C.byref(ms)), "rts_bvh_build_device_ex")

@@ -1,5 +1,7 @@
 // BVH build on the GPU: an alternative PRODUCER of the packed node stream of SURVEY.md
-// Appendix A.  Two topologies over the Morton order of the triangle centroids (63-bit codes, hipcub radix sort):
+// Appendix A.
+//   RTS_GPU_BUILD_SAH   the reference's own split rule for every node, all ranges of a level at once (default; below)
+// Three topologies over the Morton order of the triangle centroids (63-bit codes, hipcub radix sort):
 //   RTS_GPU_BUILD_LBVH  Karras' parallel hierarchy (one kernel) + bottom-up bounds: fastest build, weakest tree
 //   RTS_GPU_BUILD_PLOC  parallel locally-ordered clustering (Meister & Bittner 2018): every cluster looks `radius`
 //                       neighbours up and down the Morton order for the partner whose union has the smallest surface
@@ -12,8 +14,8 @@
 //   * depth-first (pre-order) numbering, left child = i+1 (cpp:222-238)
 //   * miss link = first index after the subtree, 0xFFFFFFFF at the end (cpp:231-236)
 //   * inner {bboxMin|0xFFFFFFFF}{bboxMax|next}, leaf {v1-v0|2N+prim}{v2-v0|next}, tail v0 per triangle (cpp:308-367)
-// The TREE is not the reference's full-sweep SAH tree (that builder is bvh_builder.cpp, byte-identical to the oracle);
-// any valid stream is a drop-in for the consumer, and masks agree with the SAH stream's up to the slab test's
+// The Morton-order TREES are not the reference's full-sweep SAH tree (bvh_builder.cpp on the host and RTS_GPU_BUILD_SAH
+// here are); any valid stream is a drop-in for the consumer, and masks agree with the SAH stream's up to the slab test's
 // non-conservativeness.
 //
 // Synchronisation: every dependency between nodes crosses a KERNEL BOUNDARY (refit sweeps are repeated launches,
@@ -56,28 +58,39 @@ __device__ __forceinline__ float decodeOrdered(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
+// Leaf boxes + the box of the centroids (the Morton grid).  The six scene-box atomics hit six addresses: reduced over the
+// wave first and skipped when the (possibly stale) current value already covers the wave -- one per triangle cost 1 ms for 1M.
 __global__ void leafBoxesKernel(Lbvh b) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= b.P) return;
-    float lo[3], hi[3];
+    const bool live = p < b.P;
+    float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 0.f, 0.f, 0.f };
     bool finite = true;
-    for (int c = 0; c < 3; ++c) {
-        const float* v = b.verts + (size_t)b.stride * b.indices[(size_t)p * 3 + c];
-        for (int k = 0; k < 3; ++k) {
-            const float x = v[k];
-            finite = finite && (__builtin_fabsf(x) < __builtin_inff());
-            lo[k] = (c == 0 || x < lo[k]) ? x : lo[k];
-            hi[k] = (c == 0 || hi[k] < x) ? x : hi[k];
+    if (live) {
+        for (int c = 0; c < 3; ++c) {
+            const float* v = b.verts + (size_t)b.stride * b.indices[(size_t)p * 3 + c];
+            for (int k = 0; k < 3; ++k) {
+                const float x = v[k];
+                finite = finite && (__builtin_fabsf(x) < __builtin_inff());
+                lo[k] = (c == 0 || x < lo[k]) ? x : lo[k];
+                hi[k] = (c == 0 || hi[k] < x) ? x : hi[k];
+            }
         }
+        if (!finite) b.flags[0] = 1;
     }
     for (int k = 0; k < 3; ++k) {
-        b.leafLo[(size_t)p * 3 + k] = lo[k];
-        b.leafHi[(size_t)p * 3 + k] = hi[k];
-        const float c = (lo[k] + hi[k]) * 0.5f;                          // centroid as in BVHBuilder (Box3::center)
-        atomicMin(&b.sceneBox[k], encodeOrdered(c));
-        atomicMax(&b.sceneBox[3 + k], encodeOrdered(c));
+        if (live) { b.leafLo[(size_t)p * 3 + k] = lo[k]; b.leafHi[(size_t)p * 3 + k] = hi[k]; }
+        const uint32_t c = encodeOrdered((lo[k] + hi[k]) * 0.5f);        // centroid as in BVHBuilder (Box3::center)
+        uint32_t mn = live ? c : 0xFFFFFFFFu, mx = live ? c : 0u;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t omn = (uint32_t)__shfl_xor((int)mn, d, 64), omx = (uint32_t)__shfl_xor((int)mx, d, 64);
+            mn = omn < mn ? omn : mn;
+            mx = omx > mx ? omx : mx;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (mn < __atomic_load_n(&b.sceneBox[k], __ATOMIC_RELAXED)) atomicMin(&b.sceneBox[k], mn);
+            if (mx > __atomic_load_n(&b.sceneBox[3 + k], __ATOMIC_RELAXED)) atomicMax(&b.sceneBox[3 + k], mx);
+        }
     }
-    if (!finite) b.flags[0] = 1;
 }
 
 __device__ __forceinline__ uint64_t spread21(uint32_t v) {                 // 21 bits -> every third bit
@@ -384,6 +397,291 @@ static void buildTopSah(uint32_t n, const uint32_t* id, const float* lo, const f
     }
 }
 
+// ---- full-sweep SAH on the GPU (RTS_GPU_BUILD_SAH) ---------------------------------------------------------------
+// The reference's own split rule (BVHBuilder.cpp:78-179) for EVERY node, level by level: all ranges ("segments") of a
+// level are split at once.  Three index lists hold the triangles of every segment sorted by the centroid on x, y and z
+// (sorted once with a stable radix sort, kept sorted by stable partitions: ties are ordered by triangle id -- the one
+// difference from the reference, whose std::sort leaves ties in an unspecified order; on meshes without equal
+// centroids the stream equals BVHBuilder's byte for byte).  Per level:
+//   1. six segmented scans (3 axes x forward / backward) of the triangle boxes  -> saL[i], saR[i]     (cpp:104-119)
+//      and a seventh in the order the range was left in by its parent's split -> the node's box, with the reference's
+//      min/max operand order (cpp:63-71: of a +0 and a -0 the later one stays)
+//   2. cost(m) = saL[m-1] * m + saR[m] * (n - m), minimum over positions (first wins), then over axes (first wins):
+//      one 64-bit atomicMin per segment on (cost bits, axis, m)                                        (cpp:121-146)
+//      ranges above `limit` triangles: spatial median on the widest axis                             (cpp:157-178)
+//   3. the new node (id = global position of the split - 1, unique), child links, "larger area first" (cpp:202-208)
+//   4. stable partition of the two other lists (exclusive sums of the "goes left" flags)
+constexpr int SCAN_ITEMS = 4, SCAN_TILE = 256 * SCAN_ITEMS;
+
+// Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the positions, so the boxes a deep
+// level gathers (few segments per eighth) stay in that XCD's L2.
+__device__ __forceinline__ uint32_t xcdContiguousBlock(uint32_t blk, uint32_t nBlocks) {
+    const uint32_t per = (nBlocks + 7) / 8, mapped = (blk & 7u) * per + (blk >> 3);
+    return mapped;                                                       // may be >= nBlocks: such a block has nothing to do
+}
+
+struct Sah {
+    uint32_t P, limit;
+    const float* leafLo; const float* leafHi;
+    float4* leafBox;                                // 2 per triangle: (lo.xyz, hi.x) (hi.yz, -, -): one 32-byte gather per box
+    uint32_t* ord[3]; uint32_t* ordOut[3];          // position -> triangle, per axis
+    uint32_t* segB; uint32_t* segE;                 // per position: its segment [begin, end)
+    uint32_t* segBOut; uint32_t* segEOut;
+    float* saL[3]; float* saR[3];                   // area of the boxes of [begin .. i] / [i .. end)
+    float* segLo; float* segHi;                     // at [begin]: the segment's box
+    unsigned long long* bestKey;                    // at [begin]: (cost bits << 32) | axis << 30 | m
+    uint32_t* splitInfo;                            // at [begin]: axis << 30 | m of the split taken this level
+    uint32_t* segParent;                            // at [begin]: parent node id * 2 + child slot, END for the root
+    uint32_t* segAxis;                              // at [begin]: axis the parent was split on (3: the root, triangle order)
+    uint32_t* side;                                 // per triangle: 1 = goes left
+    uint32_t* cnt[3];                               // exclusive sum of side over the list of each axis
+    void* boxAggs; uint32_t* cntAggs;               // per-block aggregates of the scans
+    uint32_t* flags;                                // [0] a segment with more than one triangle was created, [1] degenerate
+    uint32_t* child; uint32_t* parent; uint32_t* leaves; float* nodeLo; float* nodeHi;
+};
+
+struct BoxAgg { float lo0, lo1, lo2, hi0, hi1, hi2; uint32_t head; };   // head: the run contains the start of a segment
+
+struct BoxOp {
+    typedef BoxAgg Agg;
+    // blockIdx.y = axis * 2 + (0 forward | 1 backward); 6 = forward in the slot order of the reference (node boxes)
+    __device__ static Agg identity() { const float inf = __builtin_inff(); return Agg{ inf, inf, inf, -inf, -inf, -inf, 0u }; }
+    __device__ static Agg combine(const Agg& a, const Agg& b) {
+        if (b.head) return b;
+        return Agg{ a.lo0 < b.lo0 ? a.lo0 : b.lo0, a.lo1 < b.lo1 ? a.lo1 : b.lo1, a.lo2 < b.lo2 ? a.lo2 : b.lo2,      // cpp:63-71
+                    a.hi0 > b.hi0 ? a.hi0 : b.hi0, a.hi1 > b.hi1 ? a.hi1 : b.hi1, a.hi2 > b.hi2 ? a.hi2 : b.hi2, a.head };
+    }
+    __device__ static Agg shflUp(const Agg& v, int d) {
+        return Agg{ __shfl_up(v.lo0, d, 64), __shfl_up(v.lo1, d, 64), __shfl_up(v.lo2, d, 64),
+                    __shfl_up(v.hi0, d, 64), __shfl_up(v.hi1, d, 64), __shfl_up(v.hi2, d, 64), (uint32_t)__shfl_up((int)v.head, d, 64) };
+    }
+    __device__ static Agg* aggs(const Sah& s) { return (Agg*)s.boxAggs; }
+    __device__ static Agg load(const Sah& s, int y, uint32_t t) {
+        const uint32_t i = (y & 1) ? s.P - 1 - t : t;
+        const uint32_t axis = y < 6 ? (uint32_t)y >> 1 : s.segAxis[s.segB[i]];
+        const uint32_t prim = axis < 3 ? s.ord[axis][i] : i;
+        const float4 p = s.leafBox[(size_t)prim * 2], q = s.leafBox[(size_t)prim * 2 + 1];
+        const uint32_t head = (y & 1) ? (i + 1 == s.segE[i]) : (i == s.segB[i]);
+        return Agg{ p.x, p.y, p.z, p.w, q.x, q.y, head };
+    }
+    __device__ static void store(const Sah& s, int y, uint32_t t, const Agg& incl, const Agg&) {
+        const uint32_t i = (y & 1) ? s.P - 1 - t : t;
+        const float lo[3] = { incl.lo0, incl.lo1, incl.lo2 }, hi[3] = { incl.hi0, incl.hi1, incl.hi2 };
+        if (y < 6) {
+            ((y & 1) ? s.saR[y >> 1] : s.saL[y >> 1])[i] = surfaceArea(lo, hi);
+        } else if (i + 1 == s.segE[i]) {                               // the whole segment: its box is the node's (cpp:190)
+            const uint32_t b = s.segB[i];
+            for (int a = 0; a < 3; ++a) { s.segLo[(size_t)b * 3 + a] = lo[a]; s.segHi[(size_t)b * 3 + a] = hi[a]; }
+        }
+    }
+};
+
+struct CountOp {
+    typedef uint32_t Agg;
+    __device__ static Agg identity() { return 0u; }
+    __device__ static Agg combine(Agg a, Agg b) { return a + b; }
+    __device__ static Agg shflUp(Agg v, int d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+    __device__ static Agg* aggs(const Sah& s) { return s.cntAggs; }
+    __device__ static Agg load(const Sah& s, int y, uint32_t t) { return s.side[s.ord[y][t]]; }
+    __device__ static void store(const Sah& s, int y, uint32_t t, Agg, Agg excl) { s.cnt[y][t] = excl; }
+};
+
+// Exclusive prefix of one value per thread over the block (in thread order; the operator need not commute) + the total.
+template <class Op, int WAVES>
+__device__ __forceinline__ void blockExclusive(const typename Op::Agg& mine, typename Op::Agg* excl, typename Op::Agg* total,
+                                               typename Op::Agg* lds) {
+    typedef typename Op::Agg A;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    A x = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const A o = Op::shflUp(x, d);
+        if (lane >= d) x = Op::combine(o, x);
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    const A prev = Op::shflUp(x, 1);
+    A pre = Op::identity(), tot = Op::identity();
+    for (int w = 0; w < WAVES; ++w) {
+        if (w == wave) pre = tot;
+        tot = Op::combine(tot, lds[w]);
+    }
+    *excl = lane == 0 ? pre : Op::combine(pre, prev);
+    *total = tot;
+    __syncthreads();
+}
+
+template <class Op>
+__global__ __launch_bounds__(256) void scanReduceKernel(Sah s, uint32_t nBlocks) {
+    typedef typename Op::Agg A;
+    __shared__ A lds[4];
+    const int y = blockIdx.y;
+    const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
+    if (blk >= nBlocks) return;
+    const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    A acc = Op::identity();
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < s.P) acc = Op::combine(acc, Op::load(s, y, base + j));
+    A excl, tot;
+    blockExclusive<Op, 4>(acc, &excl, &tot, lds);
+    if (threadIdx.x == 0) Op::aggs(s)[(size_t)y * nBlocks + blk] = tot;
+}
+
+template <class Op>
+__global__ __launch_bounds__(1024) void scanBlocksKernel(Sah s, uint32_t nBlocks) {     // aggregates -> what enters each block
+    typedef typename Op::Agg A;
+    __shared__ A lds[16];
+    A* aggs = Op::aggs(s) + (size_t)blockIdx.x * nBlocks;
+    A carry = Op::identity();
+    for (uint32_t c = 0; c < nBlocks; c += 1024) {
+        const uint32_t idx = c + threadIdx.x;
+        const A v = idx < nBlocks ? aggs[idx] : Op::identity();
+        A excl, tot;
+        blockExclusive<Op, 16>(v, &excl, &tot, lds);
+        if (idx < nBlocks) aggs[idx] = Op::combine(carry, excl);
+        carry = Op::combine(carry, tot);
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(256) void scanApplyKernel(Sah s, uint32_t nBlocks) {
+    typedef typename Op::Agg A;
+    __shared__ A lds[4];
+    const int y = blockIdx.y;
+    const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
+    if (blk >= nBlocks) return;
+    const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    A incl[SCAN_ITEMS];
+    A acc = Op::identity();
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < s.P) acc = Op::combine(acc, Op::load(s, y, base + j));
+        incl[j] = acc;
+    }
+    A excl, tot;
+    blockExclusive<Op, 4>(acc, &excl, &tot, lds);
+    const A pre = Op::combine(Op::aggs(s)[(size_t)y * nBlocks + blk], excl);
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < s.P) Op::store(s, y, base + j, Op::combine(pre, incl[j]), j ? Op::combine(pre, incl[j - 1]) : pre);
+}
+
+__device__ __forceinline__ int widestAxis(const float* lo, const float* hi) {      // first maximum wins (cpp:157-160)
+    const float ext[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
+    int major = 0;
+    for (int k = 1; k < 3; ++k) if (ext[major] < ext[k]) major = k;
+    return major;
+}
+
+__global__ __launch_bounds__(256) void sahCostKernel(Sah s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long none = ~0ull;
+    unsigned long long key = none;
+    uint32_t b = END;
+    if (i < s.P) {
+        b = s.segB[i];
+        const uint32_t e = s.segE[i], n = e - b;
+        if (n > 1 && n <= s.limit) {
+            if (i + 1 < e) {
+                const uint32_t m = i - b + 1;                            // split after position i
+                for (int a = 0; a < 3; ++a) {
+                    const float cost = (s.saL[a][i] * (float)m + s.saR[a][i + 1] * (float)(n - m)) + 0.0f;     // cpp:121-123 (-0 -> +0: the key orders bits)
+                    if (cost < 3.402823466e+38f) {                      // cpp:119,124: bestCost starts at FLT_MAX
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)a << 30) | m;
+                        key = k < key ? k : key;
+                    }
+                }
+            }
+        } else if (n > 1) {                                              // spatial median (cpp:157-178)
+            const int major = widestAxis(s.segLo + (size_t)b * 3, s.segHi + (size_t)b * 3);
+            const float splitPos = (s.segLo[(size_t)b * 3 + major] + s.segHi[(size_t)b * 3 + major]) * 0.5f;
+            if (i > b) {
+                const uint32_t prim = s.ord[major][i];
+                const float c = (s.leafLo[(size_t)prim * 3 + major] + s.leafHi[(size_t)prim * 3 + major]) * 0.5f;
+                if (c >= splitPos) key = ((unsigned long long)major << 30) | (i - b);
+            }
+        }
+    }
+    // one atomic per wave when the wave lies inside one segment; a stale read of the current minimum only costs an atomic
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
+    if (__all(b == b0)) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(key, d, 64);
+            key = o < key ? o : key;
+        }
+        if ((threadIdx.x & 63) != 0) key = none;
+    }
+    if (key != none && key < __atomic_load_n(&s.bestKey[b], __ATOMIC_RELAXED)) atomicMin(&s.bestKey[b], key);
+}
+
+__global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.P) return;
+    const uint32_t b = s.segB[i], e = s.segE[i], n = e - b;
+    if (n <= 1) return;
+    const unsigned long long key = s.bestKey[b];
+    uint32_t axis, m;
+    if (key != ~0ull) { axis = (uint32_t)(key >> 30) & 3u; m = (uint32_t)key & 0x3FFFFFFFu; }
+    else if (n > s.limit) { axis = (uint32_t)widestAxis(s.segLo + (size_t)b * 3, s.segHi + (size_t)b * 3); m = n - 1; }   // cpp:178
+    else { s.flags[1] = 1; return; }                                     // no finite cost: the reference would not terminate (E-4/E-5)
+    const uint32_t prim = s.ord[axis][i];
+    s.side[prim] = (i - b) < m ? 1u : 0u;
+    if (i != b) return;
+    const uint32_t id = b + m - 1;                                       // one node per gap between two positions
+    const uint32_t up = s.segParent[b];
+    s.parent[id] = up == END ? END : up >> 1;
+    if (up != END) s.child[up] = id;
+    s.leaves[id] = n;
+    for (int a = 0; a < 3; ++a) { s.nodeLo[(size_t)id * 3 + a] = s.segLo[(size_t)b * 3 + a]; s.nodeHi[(size_t)id * 3 + a] = s.segHi[(size_t)b * 3 + a]; }
+    const uint32_t rightFirst = s.saR[axis][b + m] > s.saL[axis][b + m - 1] ? 1u : 0u;      // cpp:205-208
+    const uint32_t slotL = 2 * id + rightFirst, slotR = 2 * id + (rightFirst ^ 1u);
+    s.splitInfo[b] = (axis << 30) | m;
+    if (m == 1) { const uint32_t leaf = s.P - 1 + s.ord[axis][b]; s.child[slotL] = leaf; s.parent[leaf] = id; }
+    else { s.segParent[b] = slotL; s.segAxis[b] = axis; s.flags[0] = 1; }
+    if (n - m == 1) { const uint32_t leaf = s.P - 1 + s.ord[axis][e - 1]; s.child[slotR] = leaf; s.parent[leaf] = id; }
+    else { s.segParent[b + m] = slotR; s.segAxis[b + m] = axis; s.flags[0] = 1; }
+}
+
+__global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t a = blockIdx.y;
+    if (i >= s.P) return;
+    const uint32_t b = s.segB[i], e = s.segE[i], n = e - b;
+    const uint32_t prim = s.ord[a][i];
+    if (n <= 1) {
+        s.ordOut[a][i] = prim;
+        if (a == 0) { s.segBOut[i] = b; s.segEOut[i] = e; }
+        return;
+    }
+    const uint32_t info = s.splitInfo[b], axis = info >> 30, m = info & 0x3FFFFFFFu;
+    uint32_t to = i;
+    if (a != axis) {                                                     // stable partition: lefts first, both in list order
+        const uint32_t lefts = s.cnt[a][i] - s.cnt[a][b];
+        to = s.side[prim] ? b + lefts : b + m + (i - b - lefts);
+    }
+    s.ordOut[a][to] = prim;
+    if (a == 0) {
+        if (i < b + m) { s.segBOut[i] = b; s.segEOut[i] = b + m; } else { s.segBOut[i] = b + m; s.segEOut[i] = e; }
+        if (i == b) { s.bestKey[b] = ~0ull; s.bestKey[b + m] = ~0ull; }
+    }
+}
+
+__global__ void sahSortKeysKernel(Sah s, int axis, uint32_t* keys, uint32_t* vals) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= s.P) return;
+    const float c = (s.leafLo[(size_t)p * 3 + axis] + s.leafHi[(size_t)p * 3 + axis]) * 0.5f;      // Box3::center
+    keys[p] = encodeOrdered(c + 0.0f);                                   // -0 and +0 compare equal in the reference's sort
+    vals[p] = p;
+}
+
+__global__ void sahInitKernel(Sah s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.P) return;
+    s.segB[i] = 0; s.segE[i] = s.P;
+    s.leafBox[(size_t)i * 2] = make_float4(s.leafLo[(size_t)i * 3], s.leafLo[(size_t)i * 3 + 1], s.leafLo[(size_t)i * 3 + 2], s.leafHi[(size_t)i * 3]);
+    s.leafBox[(size_t)i * 2 + 1] = make_float4(s.leafHi[(size_t)i * 3 + 1], s.leafHi[(size_t)i * 3 + 2], 0.f, 0.f);
+    s.bestKey[i] = ~0ull;
+    s.side[i] = 0;
+    if (i == 0) { s.segParent[0] = END; s.segAxis[0] = 3; }
+}
+
 __global__ void setParentsKernel(Lbvh b, const uint32_t* pairs, uint32_t nPairs, uint32_t root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nPairs) b.parent[pairs[2 * i]] = pairs[2 * i + 1];
@@ -440,7 +738,7 @@ __global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P 
 }
 
 struct DeviceArena {            // frees everything it handed out, whatever path leaves the function
-    void* ptrs[40]; int n = 0;
+    void* ptrs[96]; int n = 0;
     hipEvent_t ev[2] = { nullptr, nullptr };
     template <typename T> hipError_t get(T** p, size_t bytes) {
         void* v = nullptr;
@@ -463,9 +761,10 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
                                        const uint32_t* indices, uint32_t P, int algorithm, uint32_t radius,
                                        rts_vec4u* out_packed, size_t out_cap, int install, float* build_ms) {
     if (!ctx || !vertices || !indices || P == 0 || stride < 3 || P > 0x0CCCCCCCu) return RTS_ERR_INVALID_ARG;
-    if ((algorithm != RTS_GPU_BUILD_LBVH && algorithm != RTS_GPU_BUILD_PLOC && algorithm != RTS_GPU_BUILD_PLOC_SAH) || radius > 256)
+    if (algorithm != RTS_GPU_BUILD_LBVH && algorithm != RTS_GPU_BUILD_PLOC && algorithm != RTS_GPU_BUILD_PLOC_SAH && algorithm != RTS_GPU_BUILD_SAH)
         return RTS_ERR_INVALID_ARG;
-    if (radius == 0) radius = 16;
+    if (algorithm != RTS_GPU_BUILD_SAH && radius > 256) return RTS_ERR_INVALID_ARG;
+    if (radius == 0) radius = algorithm == RTS_GPU_BUILD_SAH ? 1000000u : 16u;      // (SAH: BVHBuilder.cpp:83)
     const size_t count = (size_t)5 * P - 2;
     if (out_packed && out_cap < count) return RTS_ERR_CAPACITY;
     for (size_t i = 0; i < (size_t)3 * P; ++i)
@@ -511,7 +810,59 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
 
     const uint64_t* sortedKeys = b.keys;
     const uint32_t* sortedOrder = b.order;
-    if (P > 1) {
+    if (P > 1 && algorithm == RTS_GPU_BUILD_SAH) {
+        Sah s{};
+        s.P = P; s.limit = radius;
+        s.leafLo = b.leafLo; s.leafHi = b.leafHi;
+        s.child = b.child; s.parent = b.parent; s.leaves = b.leaves; s.nodeLo = b.nodeLo; s.nodeHi = b.nodeHi;
+        const uint32_t nBlocks = (P + SCAN_TILE - 1) / SCAN_TILE;
+        uint32_t *keys32, *keysAlt32, *identity;
+        LB_HIP(arena.get(&keys32, (size_t)P * 4)); LB_HIP(arena.get(&keysAlt32, (size_t)P * 4)); LB_HIP(arena.get(&identity, (size_t)P * 4));
+        for (int a = 0; a < 3; ++a) {
+            LB_HIP(arena.get(&s.ord[a], (size_t)P * 4)); LB_HIP(arena.get(&s.ordOut[a], (size_t)P * 4));
+            LB_HIP(arena.get(&s.saL[a], (size_t)P * 4)); LB_HIP(arena.get(&s.saR[a], (size_t)P * 4));
+            LB_HIP(arena.get(&s.cnt[a], (size_t)P * 4));
+        }
+        LB_HIP(arena.get(&s.segB, (size_t)P * 4)); LB_HIP(arena.get(&s.segE, (size_t)P * 4));
+        LB_HIP(arena.get(&s.segBOut, (size_t)P * 4)); LB_HIP(arena.get(&s.segEOut, (size_t)P * 4));
+        LB_HIP(arena.get(&s.segLo, (size_t)P * 12)); LB_HIP(arena.get(&s.segHi, (size_t)P * 12));
+        LB_HIP(arena.get(&s.leafBox, (size_t)P * 32));
+        LB_HIP(arena.get(&s.bestKey, (size_t)P * 8));
+        LB_HIP(arena.get(&s.splitInfo, (size_t)P * 4)); LB_HIP(arena.get(&s.segParent, (size_t)P * 4)); LB_HIP(arena.get(&s.segAxis, (size_t)P * 4)); LB_HIP(arena.get(&s.side, (size_t)P * 4));
+        LB_HIP(arena.get(&s.boxAggs, (size_t)nBlocks * 7 * sizeof(BoxAgg))); LB_HIP(arena.get(&s.cntAggs, (size_t)nBlocks * 3 * 4));
+        LB_HIP(arena.get(&s.flags, 16));
+        size_t tempBytes = 0;
+        LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keys32, keysAlt32, identity, s.ord[0], (int)P, 0, 32, nullptr));
+        void* temp;
+        LB_HIP(arena.get(&temp, tempBytes));
+        for (int a = 0; a < 3; ++a) {                                   // stable: equal centroids stay in triangle order
+            hipLaunchKernelGGL(sahSortKeysKernel, gridP, block, 0, nullptr, s, a, keys32, identity);
+            LB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keys32, keysAlt32, identity, s.ord[a], (int)P, 0, 32, nullptr));
+        }
+        hipLaunchKernelGGL(sahInitKernel, gridP, block, 0, nullptr, s);
+        const uint32_t scanGrid = (nBlocks + 7) / 8 * 8;               // (xcdContiguousBlock)
+        const dim3 gridBox(scanGrid, 7), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
+        for (uint32_t level = 0;; ++level) {
+            if (level > 16384u) { arena.release(); return RTS_ERR_DEGENERATE; }      // (a chain: thousands of equal boxes)
+            LB_HIP(hipMemsetAsync(s.flags, 0, 16, nullptr));
+            hipLaunchKernelGGL(scanReduceKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(scanBlocksKernel<BoxOp>, dim3(7), dim3(1024), 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(scanApplyKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(sahCostKernel, gridP, block, 0, nullptr, s);
+            hipLaunchKernelGGL(sahSplitKernel, gridP, block, 0, nullptr, s);
+            uint32_t f[2] = { 0, 0 };
+            LB_HIP(hipMemcpy(f, s.flags, 8, hipMemcpyDeviceToHost));
+            if (f[1]) { arena.release(); return RTS_ERR_DEGENERATE; }
+            if (!f[0]) break;                                           // every child made by this level is a leaf
+            hipLaunchKernelGGL(scanReduceKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(scanBlocksKernel<CountOp>, dim3(3), dim3(1024), 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(scanApplyKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(sahScatterKernel, gridScatter, block, 0, nullptr, s);
+            for (int a = 0; a < 3; ++a) std::swap(s.ord[a], s.ordOut[a]);
+            std::swap(s.segB, s.segBOut); std::swap(s.segE, s.segEOut);
+        }
+        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, identity, (uint32_t*)d_packed);
+    } else if (P > 1) {
         hipLaunchKernelGGL(mortonKernel, gridP, block, 0, nullptr, b);
         size_t tempBytes = 0;
         LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, b.keys, keysAlt, b.order, orderAlt, (int)P, 0, 63, nullptr));
@@ -615,6 +966,6 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
 extern "C" int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
                                     const uint32_t* indices, uint32_t P, rts_vec4u* out_packed, size_t out_cap,
                                     int install, float* build_ms) {
-    return rts_bvh_build_device_ex(ctx, vertices, vertex_floats, stride, indices, P, RTS_GPU_BUILD_PLOC, 16, out_packed,
+    return rts_bvh_build_device_ex(ctx, vertices, vertex_floats, stride, indices, P, RTS_GPU_BUILD_SAH, 0, out_packed,
                                    out_cap, install, build_ms);
 }

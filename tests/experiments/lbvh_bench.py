@@ -18,14 +18,15 @@ def main():
             api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, want_packed=False)   # warm-up (hipcub, allocs)
             base = None
             for name, algo, radius in (("SAH (host build)", None, 0), ("LBVH", "lbvh", 0), ("PLOC r=8", "ploc", 8), ("PLOC r=16", "ploc", 16),
-                                       ("PLOC r=32", "ploc", 32), ("PLOC r=16 + SAH top", "ploc_sah", 16)):
+                                       ("PLOC r=32", "ploc", 32), ("PLOC r=16 + SAH top", "ploc_sah", 16), ("SAH on the device", "sah", 0)):
                 if algo is None:
                     ctx.set_bvh(wl.packed)
                     ref, ms, wall = wl.packed, wl.build_seconds * 1e3, wl.build_seconds * 1e3
                 else:
                     t0 = time.time()
-                    ref, ms = api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, install=True, algorithm=algo, radius=radius or 16)
+                    ref, ms = api.bvh_build_device(ctx, wl.vertices, 8, wl.indices, wl.prim_count, install=True, algorithm=algo, radius=radius)
                     wall = (time.time() - t0) * 1e3
+                same = "" if algo != "sah" else f", stream == the host builder's: {bool((ref == wl.packed).all())}"
                 want, V, L = oracle.shadow_mask(ref, wl.constants.as_array(), lt, wl.positions, W, H)
                 for _ in range(200):
                     ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
@@ -39,7 +40,7 @@ def main():
                 base = base or (t, V)
                 print(f"[{cfg}] {name}: build {ms:.2f} ms on the device ({wall:.0f} ms wall); trace {t:.4f} ms ({t / base[0]:.2f}x SAH), "
                       f"nodes/ray {V / want.size:.1f} ({V / base[1]:.2f}x SAH), tris/ray {L / want.size:.2f}, "
-                      f"mismatches vs oracle on the same stream {int((got != want).sum())}", flush=True)
+                      f"mismatches vs oracle on the same stream {int((got != want).sum())}{same}", flush=True)
 
 
 if __name__ == "__main__":

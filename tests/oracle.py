@@ -19,6 +19,8 @@ _o.orc_packed_count.restype = C.c_uint64
 _o.orc_packed_count.argtypes = [C.c_uint32]
 _o.orc_bvh_build.restype = C.c_int
 _o.orc_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+_o.orc_bvh_build_ties_by_prim.restype = C.c_int
+_o.orc_bvh_build_ties_by_prim.argtypes = _o.orc_bvh_build.argtypes
 _o.orc_any_hit.restype = C.c_int
 _o.orc_any_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 _o.orc_trace_rays.restype = None
@@ -82,14 +84,15 @@ def max_threads():
     return int(_o.orc_max_threads())
 
 
-def bvh_build(vertices, stride, indices, prim_count, sah_limit=1000000, want_nodes=False):
+def bvh_build(vertices, stride, indices, prim_count, sah_limit=1000000, want_nodes=False, ties_by_prim=False):
+    """ties_by_prim: equal centroids ordered by triangle id (the rule of the GPU SAH builder) instead of std::sort's."""
     vertices = np.ascontiguousarray(vertices, np.float32)
     indices = np.ascontiguousarray(indices, np.uint32)
     n = int(_o.orc_packed_count(prim_count))
     packed = np.zeros((n, 4), np.uint32)
     nodes = np.zeros((2 * prim_count - 1, 8), np.uint32) if want_nodes else None
-    st = _o.orc_bvh_build(_p(vertices), stride, _p(indices), prim_count, sah_limit, _p(packed),
-                          _p(nodes) if want_nodes else None)
+    fn = _o.orc_bvh_build_ties_by_prim if ties_by_prim else _o.orc_bvh_build
+    st = fn(_p(vertices), stride, _p(indices), prim_count, sah_limit, _p(packed), _p(nodes) if want_nodes else None)
     if st != 0:
         raise ValueError("oracle builder rejected the input")
     return (packed, nodes) if want_nodes else packed

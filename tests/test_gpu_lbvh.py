@@ -1,5 +1,6 @@
-"""GPU: the BVH producers on the GPU (rts_bvh_build_device[_ex]: PLOC and LBVH).  Their trees are not BVHBuilder's SAH tree,
-so the checks are: the stream obeys every layout rule of Appendix A (same invariants the oracle's builder is held to),
+"""GPU: the BVH producers on the GPU (rts_bvh_build_device[_ex]).  "sah" is BVHBuilder's own rule run level by
+level on the device and is held to the oracle's builder byte for byte (ties ordered by triangle id).  The trees of PLOC, LBVH and
+PLOC + SAH top are not BVHBuilder's, so for them the checks are: the stream obeys every layout rule of Appendix A (same invariants the oracle's builder is held to),
 the kernels traced against it equal the CPU oracle traced against THE SAME stream bit for bit, and the resulting mask
 agrees with the SAH stream's mask up to the slab test's non-conservativeness."""
 import numpy as np
@@ -25,7 +26,7 @@ def _soup(n, seed):
     return (c + (rs.random_sample((n, 3, 3)) - 0.5) * 1.5).astype(np.float32).reshape(-1, 3), np.arange(3 * n, dtype=np.uint32)
 
 
-ALGOS = ["ploc", "lbvh", "ploc_sah"]
+ALGOS = ["ploc", "lbvh", "ploc_sah", "sah"]
 
 
 @pytest.mark.parametrize("algo", ALGOS)
@@ -62,6 +63,62 @@ def test_duplicates_grids_and_flat_scenes(ctx, algo):
     assert (packed2 == packed).all()
 
 
+@pytest.mark.parametrize("n,seed", [(2, 1), (3, 2), (17, 3), (1000, 4), (30011, 5), (150001, 6)])
+def test_device_sah_equals_bvhbuilder_byte_for_byte_without_ties(ctx, n, seed):
+    """Random soups have no two equal centroids, so the order of ties cannot matter: the stream built on the device must BE
+    the reference builder's stream (oracle restatement and the product's host BVHBuilder)."""
+    v, idx = _soup(n, seed)
+    packed, _ = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
+    assert (packed == oracle.bvh_build(v, 3, idx, n)).all()
+    assert (packed == api.BVHBuilder().build(v, 3, idx, n).m_packedNodes).all()
+    again, _ = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
+    assert (again == packed).all()
+
+
+def test_device_sah_with_ties_equals_the_oracle_with_ties_by_triangle_id(ctx):
+    """Grids, duplicated triangles and the 250 k-triangle atrium are full of equal centroids; there the device builder is
+    specified by `ties_by_prim` (oracle/rts_oracle.cpp CtrLess) and must match it byte for byte -- and -0 == +0."""
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    cases = [("duplicates", np.tile(tri, (300, 1)), 3, np.arange(900, dtype=np.uint32), 300)]
+    t0 = np.array([[0.0, 0, 0], [0.0, 1, 0], [0.0, 0, 1]], np.float32)            # in the plane x = +0
+    t1 = t0 + np.float32([0, 0.5, 0])
+    t1[:, 0] = np.float32(-0.0)                                                   # same size, in the plane x = -0
+    z = np.concatenate([t0, t1, t1 + np.float32([0, 10, 0]), t0 + np.float32([0, 10, 0])])
+    z[6:9, 0] = np.float32(-0.0)
+    assert np.signbit(z[3:9, 0]).all() and not np.signbit(z[[0, 1, 2, 9, 10, 11], 0]).any()
+    cases.append(("signed zeros", z, 3, np.arange(12, dtype=np.uint32), 4))      # x centroids +0, -0, -0, +0: all equal
+    for sc in (scenes.terrain(24), scenes.cornell(), scenes.SCENES["atrium"]()):
+        fv, fi = sc.flat()
+        cases.append((sc.name, fv, 8, fi, sc.triangle_count))
+    for name, v, stride, idx, P in cases:
+        packed, ms = api.bvh_build_device(ctx, v, stride, idx, P, algorithm="sah")
+        want = oracle.bvh_build(v, stride, idx, P, ties_by_prim=True)
+        assert (packed == want).all(), name
+        print(f"{name}: {P} triangles, {ms:.2f} ms on the device")
+
+
+@pytest.mark.parametrize("limit", [1, 7, 64, 5000])
+def test_device_sah_median_branch(ctx, limit):
+    """`radius` = the range size above which the spatial median is used (the reference's 1 000 000, cpp:83,157-178)."""
+    v, idx = _soup(20000, 31)
+    packed, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="sah", radius=limit)
+    assert (packed == oracle.bvh_build(v, 3, idx, 20000, sah_limit=limit)).all()
+    sc = scenes.terrain(30)
+    fv, fi = sc.flat()
+    packed, _ = api.bvh_build_device(ctx, fv, 8, fi, sc.triangle_count, algorithm="sah", radius=limit)
+    assert (packed == oracle.bvh_build(fv, 8, fi, sc.triangle_count, sah_limit=limit, ties_by_prim=True)).all()
+
+
+def test_device_sah_reports_what_the_reference_cannot_finish(ctx):
+    """Extents whose surface areas overflow leave no cost below FLT_MAX: the reference recurses for ever (SURVEY E-4/E-5), the
+    host builder returns RTS_ERR_DEGENERATE (tests/test_builder.py) and so does the device builder."""
+    v, idx = _soup(64, 5)
+    v = v * np.float32(1e19)
+    with pytest.raises(api.RtsError) as e:
+        api.bvh_build_device(ctx, v, 3, idx, 64, algorithm="sah")
+    assert e.value.status == 6
+
+
 def test_sah_top_over_ploc_clusters_on_a_big_scene(ctx):
     """"ploc_sah" only differs from "ploc" above 65 536 clusters: the 250 k-triangle atrium exercises the host top (layout
     rules, determinism, parity of a trace through it)."""
@@ -91,14 +148,16 @@ def test_ploc_is_deterministic_and_radius_is_a_knob(ctx):
     """Internal node ids come from an atomic counter, the emitted stream does not depend on them: two builds are byte-equal.
     Any radius gives a valid stream; radius 1 is plain neighbour merging."""
     v, idx = _soup(20000, 21)
-    a, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)
-    b, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)
+    a, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="ploc")
+    b, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="ploc")
     assert (a == b).all()
     for radius in (1, 4, 64, 256):
-        p, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, radius=radius)
+        p, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="ploc", radius=radius)
         assert api.bvh_validate(p) == 20000
     with pytest.raises(api.RtsError):
-        api.bvh_build_device(ctx, v, 3, idx, 20000, radius=1000)
+        api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="ploc", radius=1000)
+    default, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)                 # rts_bvh_build_device's default: BVHBuilder's tree
+    assert (default == oracle.bvh_build(v, 3, idx, 20000)).all()
 
 
 @pytest.mark.parametrize("algo", ALGOS)
