@@ -29,7 +29,9 @@ enum {
     RTS_ERR_NO_BVH      = 4, /* trace called before rts_ctx_set_bvh                         */
     RTS_ERR_BAD_BVH     = 5, /* packed buffer fails structural validation                   */
     RTS_ERR_DEGENERATE  = 6, /* finite vertices whose extents overflow the SAH cost to +inf: no split position
-                                exists (reference: unbounded recursion, SURVEY E-4/E-5)      */
+                                exists (reference: unbounded recursion, SURVEY E-4/E-5); RTS_GPU_BUILD_SAH also: a
+                                tree deeper than 262 144 levels (hundreds of thousands of triangles with EQUAL boxes split
+                                off one per level; the reference recurses as deep as that chain is long)        */
     RTS_ERR_HIP         = 100 /* 100 + hipError_t                                           */
 };
 const char* rts_status_string(int status);

@@ -75,7 +75,7 @@ const char* rts_status_string(int s) {
     case RTS_ERR_NONFINITE: return "non-finite vertex";
     case RTS_ERR_NO_BVH: return "no BVH set on context";
     case RTS_ERR_BAD_BVH: return "packed BVH failed validation";
-    case RTS_ERR_DEGENERATE: return "SAH cost overflow: no split position (coordinate extents too large)";
+    case RTS_ERR_DEGENERATE: return "degenerate input: no SAH split position (coordinate extents overflow the cost) or a chain of equal boxes deeper than 262144 levels";
     default: break;
     }
     if (s >= RTS_ERR_HIP) return hipGetErrorString((hipError_t)(s - RTS_ERR_HIP));

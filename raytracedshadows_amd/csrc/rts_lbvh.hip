@@ -696,7 +696,7 @@ __global__ void emitKernel(Lbvh b, const uint32_t* order, uint32_t* packed) {
     const bool leaf = id >= P - 1;
     const uint32_t size = leaf ? 1u : 2u * b.leaves[id] - 1u;
     uint32_t index = 0, cur = id;
-    for (uint32_t guard = 0; guard < 4096 && b.parent[cur] != END; ++guard) {
+    for (uint32_t guard = 0; guard < N && b.parent[cur] != END; ++guard) {      // (a chain of equal boxes is as deep as it is long)
         const uint32_t par = b.parent[cur];
         index += 1;
         if (b.child[2 * par + 1] == cur) {                       // second child: the first one's subtree comes before
@@ -843,7 +843,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         const uint32_t scanGrid = (nBlocks + 7) / 8 * 8;               // (xcdContiguousBlock)
         const dim3 gridBox(scanGrid, 7), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
         for (uint32_t level = 0;; ++level) {
-            if (level > 16384u) { arena.release(); return RTS_ERR_DEGENERATE; }      // (a chain: thousands of equal boxes)
+            if (level > 262144u) { arena.release(); return RTS_ERR_DEGENERATE; }     // (a chain of equal boxes: a level each, ~0.1 ms)
             LB_HIP(hipMemsetAsync(s.flags, 0, 16, nullptr));
             hipLaunchKernelGGL(scanReduceKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<BoxOp>, dim3(7), dim3(1024), 0, nullptr, s, nBlocks);

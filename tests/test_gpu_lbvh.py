@@ -79,7 +79,7 @@ def test_device_sah_with_ties_equals_the_oracle_with_ties_by_triangle_id(ctx):
     """Grids, duplicated triangles and the 250 k-triangle atrium are full of equal centroids; there the device builder is
     specified by `ties_by_prim` (oracle/rts_oracle.cpp CtrLess) and must match it byte for byte -- and -0 == +0."""
     tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
-    cases = [("duplicates", np.tile(tri, (300, 1)), 3, np.arange(900, dtype=np.uint32), 300)]
+    cases = [("duplicates", np.tile(tri, (4500, 1)), 3, np.arange(13500, dtype=np.uint32), 4500)]       # a chain 4 499 levels deep
     t0 = np.array([[0.0, 0, 0], [0.0, 1, 0], [0.0, 0, 1]], np.float32)            # in the plane x = +0
     t1 = t0 + np.float32([0, 0.5, 0])
     t1[:, 0] = np.float32(-0.0)                                                   # same size, in the plane x = -0
