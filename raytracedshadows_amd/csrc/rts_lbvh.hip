@@ -410,7 +410,9 @@ static void buildTopSah(uint32_t n, const uint32_t* id, const float* lo, const f
 //      one 64-bit atomicMin per segment on (cost bits, axis, m)                                        (cpp:121-146)
 //      ranges above `limit` triangles: spatial median on the widest axis                             (cpp:157-178)
 //   3. the new node (id = global position of the split - 1, unique), child links, "larger area first" (cpp:202-208)
-//   4. stable partition of the two other lists (exclusive sums of the "goes left" flags)
+//   4. stable partition of the two other lists (exclusive sums of the "goes left" flags); the boxes travel with their
+//      list entries, one array per component, so every scan streams coalesced floats (gathering 32-byte boxes by
+//      triangle id, or reading them as float4 pairs 128 B apart per lane, made the scans twice as slow)
 constexpr int SCAN_ITEMS = 4, SCAN_TILE = 256 * SCAN_ITEMS;
 
 // Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the positions, so the boxes a deep
@@ -423,8 +425,11 @@ __device__ __forceinline__ uint32_t xcdContiguousBlock(uint32_t blk, uint32_t nB
 struct Sah {
     uint32_t P, limit;
     const float* leafLo; const float* leafHi;
-    float4* leafBox;                                // 2 per triangle: (lo.xyz, hi.x) (hi.yz, -, -): one 32-byte gather per box
     uint32_t* ord[3]; uint32_t* ordOut[3];          // position -> triangle, per axis
+    float* bc[4][6]; float* bcOut[3][6];            // the triangles' boxes IN LIST ORDER, one array per component (lo.xyz,
+                                                    // hi.xyz): they move with the partition, so a thread's four consecutive
+                                                    // positions are 16 contiguous bytes per component and a wave's loads are
+                                                    // coalesced (list 3 = triangle order, the slot order of the root)
     uint32_t* segB; uint32_t* segE;                 // per position: its segment [begin, end)
     uint32_t* segBOut; uint32_t* segEOut;
     float* saL[3]; float* saR[3];                   // area of the boxes of [begin .. i] / [i .. end)
@@ -432,7 +437,7 @@ struct Sah {
     unsigned long long* bestKey;                    // at [begin]: (cost bits << 32) | axis << 30 | m
     uint32_t* splitInfo;                            // at [begin]: axis << 30 | m of the split taken this level
     uint32_t* segParent;                            // at [begin]: parent node id * 2 + child slot, END for the root
-    uint32_t* segAxis;                              // at [begin]: axis the parent was split on (3: the root, triangle order)
+    uint32_t* posAxis; uint32_t* posAxisOut;        // per position: axis its segment's parent was split on (3: the root)
     uint32_t* side;                                 // per triangle: 1 = goes left
     uint32_t* cnt[3];                               // exclusive sum of side over the list of each axis
     void* boxAggs; uint32_t* cntAggs;               // per-block aggregates of the scans
@@ -458,11 +463,10 @@ struct BoxOp {
     __device__ static Agg* aggs(const Sah& s) { return (Agg*)s.boxAggs; }
     __device__ static Agg load(const Sah& s, int y, uint32_t t) {
         const uint32_t i = (y & 1) ? s.P - 1 - t : t;
-        const uint32_t axis = y < 6 ? (uint32_t)y >> 1 : s.segAxis[s.segB[i]];
-        const uint32_t prim = axis < 3 ? s.ord[axis][i] : i;
-        const float4 p = s.leafBox[(size_t)prim * 2], q = s.leafBox[(size_t)prim * 2 + 1];
+        const uint32_t axis = y < 6 ? (uint32_t)y >> 1 : s.posAxis[i];
+        float* const* src = s.bc[axis];
         const uint32_t head = (y & 1) ? (i + 1 == s.segE[i]) : (i == s.segB[i]);
-        return Agg{ p.x, p.y, p.z, p.w, q.x, q.y, head };
+        return Agg{ src[0][i], src[1][i], src[2][i], src[3][i], src[4][i], src[5][i], head };
     }
     __device__ static void store(const Sah& s, int y, uint32_t t, const Agg& incl, const Agg&) {
         const uint32_t i = (y & 1) ? s.P - 1 - t : t;
@@ -518,9 +522,14 @@ __global__ __launch_bounds__(256) void scanReduceKernel(Sah s, uint32_t nBlocks)
     const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
     if (blk >= nBlocks) return;
     const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    A item[SCAN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)                                 // no branch around a load: all of them are in flight together
+        item[j] = Op::load(s, y, base + j < s.P ? base + j : s.P - 1);
     A acc = Op::identity();
+#pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j)
-        if (base + j < s.P) acc = Op::combine(acc, Op::load(s, y, base + j));
+        if (base + j < s.P) acc = Op::combine(acc, item[j]);
     A excl, tot;
     blockExclusive<Op, 4>(acc, &excl, &tot, lds);
     if (threadIdx.x == 0) Op::aggs(s)[(size_t)y * nBlocks + blk] = tot;
@@ -551,9 +560,13 @@ __global__ __launch_bounds__(256) void scanApplyKernel(Sah s, uint32_t nBlocks) 
     if (blk >= nBlocks) return;
     const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     A incl[SCAN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        incl[j] = Op::load(s, y, base + j < s.P ? base + j : s.P - 1);
     A acc = Op::identity();
+#pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < s.P) acc = Op::combine(acc, Op::load(s, y, base + j));
+        if (base + j < s.P) acc = Op::combine(acc, incl[j]);
         incl[j] = acc;
     }
     A excl, tot;
@@ -634,9 +647,9 @@ __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
     const uint32_t slotL = 2 * id + rightFirst, slotR = 2 * id + (rightFirst ^ 1u);
     s.splitInfo[b] = (axis << 30) | m;
     if (m == 1) { const uint32_t leaf = s.P - 1 + s.ord[axis][b]; s.child[slotL] = leaf; s.parent[leaf] = id; }
-    else { s.segParent[b] = slotL; s.segAxis[b] = axis; s.flags[0] = 1; }
+    else { s.segParent[b] = slotL; s.flags[0] = 1; }
     if (n - m == 1) { const uint32_t leaf = s.P - 1 + s.ord[axis][e - 1]; s.child[slotR] = leaf; s.parent[leaf] = id; }
-    else { s.segParent[b + m] = slotR; s.segAxis[b + m] = axis; s.flags[0] = 1; }
+    else { s.segParent[b + m] = slotR; s.flags[0] = 1; }
 }
 
 __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
@@ -645,9 +658,12 @@ __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
     if (i >= s.P) return;
     const uint32_t b = s.segB[i], e = s.segE[i], n = e - b;
     const uint32_t prim = s.ord[a][i];
+    float c[6];
+    for (int k = 0; k < 6; ++k) c[k] = s.bc[a][k][i];
     if (n <= 1) {
         s.ordOut[a][i] = prim;
-        if (a == 0) { s.segBOut[i] = b; s.segEOut[i] = e; }
+        for (int k = 0; k < 6; ++k) s.bcOut[a][k][i] = c[k];
+        if (a == 0) { s.segBOut[i] = b; s.segEOut[i] = e; s.posAxisOut[i] = s.posAxis[i]; }
         return;
     }
     const uint32_t info = s.splitInfo[b], axis = info >> 30, m = info & 0x3FFFFFFFu;
@@ -657,7 +673,9 @@ __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
         to = s.side[prim] ? b + lefts : b + m + (i - b - lefts);
     }
     s.ordOut[a][to] = prim;
+    for (int k = 0; k < 6; ++k) s.bcOut[a][k][to] = c[k];
     if (a == 0) {
+        s.posAxisOut[i] = axis;
         if (i < b + m) { s.segBOut[i] = b; s.segEOut[i] = b + m; } else { s.segBOut[i] = b + m; s.segEOut[i] = e; }
         if (i == b) { s.bestKey[b] = ~0ull; s.bestKey[b + m] = ~0ull; }
     }
@@ -671,15 +689,22 @@ __global__ void sahSortKeysKernel(Sah s, int axis, uint32_t* keys, uint32_t* val
     vals[p] = p;
 }
 
+__global__ void sahListBoxesKernel(Sah s) {                              // boxes into list order, once
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t a = blockIdx.y;
+    if (i >= s.P) return;
+    const uint32_t prim = a < 3 ? s.ord[a][i] : i;
+    for (int k = 0; k < 3; ++k) { s.bc[a][k][i] = s.leafLo[(size_t)prim * 3 + k]; s.bc[a][3 + k][i] = s.leafHi[(size_t)prim * 3 + k]; }
+}
+
 __global__ void sahInitKernel(Sah s) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.P) return;
     s.segB[i] = 0; s.segE[i] = s.P;
-    s.leafBox[(size_t)i * 2] = make_float4(s.leafLo[(size_t)i * 3], s.leafLo[(size_t)i * 3 + 1], s.leafLo[(size_t)i * 3 + 2], s.leafHi[(size_t)i * 3]);
-    s.leafBox[(size_t)i * 2 + 1] = make_float4(s.leafHi[(size_t)i * 3 + 1], s.leafHi[(size_t)i * 3 + 2], 0.f, 0.f);
     s.bestKey[i] = ~0ull;
     s.side[i] = 0;
-    if (i == 0) { s.segParent[0] = END; s.segAxis[0] = 3; }
+    s.posAxis[i] = 3;
+    if (i == 0) s.segParent[0] = END;
 }
 
 __global__ void setParentsKernel(Lbvh b, const uint32_t* pairs, uint32_t nPairs, uint32_t root) {
@@ -823,12 +848,15 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             LB_HIP(arena.get(&s.saL[a], (size_t)P * 4)); LB_HIP(arena.get(&s.saR[a], (size_t)P * 4));
             LB_HIP(arena.get(&s.cnt[a], (size_t)P * 4));
         }
+        float* comps;                                                   // 4 lists + 3 partition targets, 6 components each
+        LB_HIP(arena.get(&comps, (size_t)P * 4 * 42));
+        for (int a = 0; a < 4; ++a) for (int k = 0; k < 6; ++k) s.bc[a][k] = comps + (size_t)P * (a * 6 + k);
+        for (int a = 0; a < 3; ++a) for (int k = 0; k < 6; ++k) s.bcOut[a][k] = comps + (size_t)P * (24 + a * 6 + k);
         LB_HIP(arena.get(&s.segB, (size_t)P * 4)); LB_HIP(arena.get(&s.segE, (size_t)P * 4));
         LB_HIP(arena.get(&s.segBOut, (size_t)P * 4)); LB_HIP(arena.get(&s.segEOut, (size_t)P * 4));
         LB_HIP(arena.get(&s.segLo, (size_t)P * 12)); LB_HIP(arena.get(&s.segHi, (size_t)P * 12));
-        LB_HIP(arena.get(&s.leafBox, (size_t)P * 32));
         LB_HIP(arena.get(&s.bestKey, (size_t)P * 8));
-        LB_HIP(arena.get(&s.splitInfo, (size_t)P * 4)); LB_HIP(arena.get(&s.segParent, (size_t)P * 4)); LB_HIP(arena.get(&s.segAxis, (size_t)P * 4)); LB_HIP(arena.get(&s.side, (size_t)P * 4));
+        LB_HIP(arena.get(&s.splitInfo, (size_t)P * 4)); LB_HIP(arena.get(&s.segParent, (size_t)P * 4)); LB_HIP(arena.get(&s.posAxis, (size_t)P * 4)); LB_HIP(arena.get(&s.posAxisOut, (size_t)P * 4)); LB_HIP(arena.get(&s.side, (size_t)P * 4));
         LB_HIP(arena.get(&s.boxAggs, (size_t)nBlocks * 7 * sizeof(BoxAgg))); LB_HIP(arena.get(&s.cntAggs, (size_t)nBlocks * 3 * 4));
         LB_HIP(arena.get(&s.flags, 16));
         size_t tempBytes = 0;
@@ -840,6 +868,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             LB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keys32, keysAlt32, identity, s.ord[a], (int)P, 0, 32, nullptr));
         }
         hipLaunchKernelGGL(sahInitKernel, gridP, block, 0, nullptr, s);
+        hipLaunchKernelGGL(sahListBoxesKernel, dim3(gridP.x, 4), block, 0, nullptr, s);
         const uint32_t scanGrid = (nBlocks + 7) / 8 * 8;               // (xcdContiguousBlock)
         const dim3 gridBox(scanGrid, 7), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
         for (uint32_t level = 0;; ++level) {
@@ -858,8 +887,11 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             hipLaunchKernelGGL(scanBlocksKernel<CountOp>, dim3(3), dim3(1024), 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanApplyKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(sahScatterKernel, gridScatter, block, 0, nullptr, s);
-            for (int a = 0; a < 3; ++a) std::swap(s.ord[a], s.ordOut[a]);
-            std::swap(s.segB, s.segBOut); std::swap(s.segE, s.segEOut);
+            for (int a = 0; a < 3; ++a) {
+                std::swap(s.ord[a], s.ordOut[a]);
+                for (int k = 0; k < 6; ++k) std::swap(s.bc[a][k], s.bcOut[a][k]);
+            }
+            std::swap(s.segB, s.segBOut); std::swap(s.segE, s.segEOut); std::swap(s.posAxis, s.posAxisOut);
         }
         hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, identity, (uint32_t*)d_packed);
     } else if (P > 1) {
