@@ -63,16 +63,46 @@ def test_duplicates_grids_and_flat_scenes(ctx, algo):
     assert (packed2 == packed).all()
 
 
+def _tie_free_soup(n, seed):
+    """Triangles whose centroids are pairwise different on every axis BY CONSTRUCTION (random floats collide: 150 000 of them
+    hold ~450 equal pairs per axis): centre = a random permutation of 1..n times 2^-10 per axis, box = centre +- h with h a
+    small multiple of 2^-12, all exactly representable, so (lo + hi) * 0.5 is the centre itself."""
+    rs = np.random.RandomState(seed)
+    c = np.stack([rs.permutation(n) + 1 for _ in range(3)], 1).astype(np.float64) / 1024.0
+    h = (rs.randint(1, 4, size=(n, 3)).astype(np.float64)) / 4096.0
+    sign = np.array([[-1, -1, -1], [1, 1, -1], [-1, 1, 1]], np.float64)              # every axis sees both -h and +h
+    v = (c[:, None, :] + sign[None, :, :] * h[:, None, :]).astype(np.float32)
+    ctr = (v.min(1) + v.max(1)) * np.float32(0.5)
+    assert all(len(np.unique(ctr[:, a])) == n for a in range(3))
+    return v.reshape(-1, 3), np.arange(3 * n, dtype=np.uint32)
+
+
 @pytest.mark.parametrize("n,seed", [(2, 1), (3, 2), (17, 3), (1000, 4), (30011, 5), (150001, 6)])
 def test_device_sah_equals_bvhbuilder_byte_for_byte_without_ties(ctx, n, seed):
-    """Random soups have no two equal centroids, so the order of ties cannot matter: the stream built on the device must BE
-    the reference builder's stream (oracle restatement and the product's host BVHBuilder)."""
-    v, idx = _soup(n, seed)
+    """No two equal centroids, so the order of ties cannot matter: the stream built on the device must BE the reference
+    builder's stream (oracle restatement, which uses std::sort as the reference does, and the product's host BVHBuilder)."""
+    v, idx = _tie_free_soup(n, seed)
     packed, _ = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
     assert (packed == oracle.bvh_build(v, 3, idx, n)).all()
     assert (packed == api.BVHBuilder().build(v, 3, idx, n).m_packedNodes).all()
     again, _ = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
     assert (again == packed).all()
+    v, idx = _soup(n, seed)                                           # random floats (a few equal centroids from 30 000 up)
+    packed, _ = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
+    assert (packed == oracle.bvh_build(v, 3, idx, n, ties_by_prim=True)).all()
+
+
+def test_device_sah_above_the_references_million_triangle_limit(ctx):
+    """1 100 003 triangles with the reference's own limit (cpp:83): the root is split at the spatial median (cpp:157-178), both
+    halves by SAH; more than 1 024 scan tiles per list.  A million random floats per axis collide tens of thousands of times,
+    so the yardstick is the oracle with ties by triangle id."""
+    n = 1100003
+    v, idx = _soup(n, 77)
+    packed, ms = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah")
+    assert (packed == oracle.bvh_build(v, 3, idx, n, ties_by_prim=True)).all()
+    packed, ms2 = api.bvh_build_device(ctx, v, 3, idx, n, algorithm="sah", radius=2000000)        # the same without the median split
+    assert (packed == oracle.bvh_build(v, 3, idx, n, sah_limit=2000000, ties_by_prim=True)).all()
+    print(f"{n} triangles: {ms:.2f} / {ms2:.2f} ms on the device")
 
 
 def test_device_sah_with_ties_equals_the_oracle_with_ties_by_triangle_id(ctx):
@@ -100,7 +130,7 @@ def test_device_sah_with_ties_equals_the_oracle_with_ties_by_triangle_id(ctx):
 @pytest.mark.parametrize("limit", [1, 7, 64, 5000])
 def test_device_sah_median_branch(ctx, limit):
     """`radius` = the range size above which the spatial median is used (the reference's 1 000 000, cpp:83,157-178)."""
-    v, idx = _soup(20000, 31)
+    v, idx = _tie_free_soup(20000, 31)
     packed, _ = api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="sah", radius=limit)
     assert (packed == oracle.bvh_build(v, 3, idx, 20000, sah_limit=limit)).all()
     sc = scenes.terrain(30)
@@ -157,7 +187,7 @@ def test_ploc_is_deterministic_and_radius_is_a_knob(ctx):
     with pytest.raises(api.RtsError):
         api.bvh_build_device(ctx, v, 3, idx, 20000, algorithm="ploc", radius=1000)
     default, _ = api.bvh_build_device(ctx, v, 3, idx, 20000)                 # rts_bvh_build_device's default: BVHBuilder's tree
-    assert (default == oracle.bvh_build(v, 3, idx, 20000)).all()
+    assert (default == oracle.bvh_build(v, 3, idx, 20000, ties_by_prim=True)).all()
 
 
 @pytest.mark.parametrize("algo", ALGOS)
