@@ -20,6 +20,7 @@ CONFIGS = {
     "courtyard_4k": ("courtyard", 3840, 2160, "point", 1),    # configs[2] on the San-Miguel-class stand-in (hard case)
     "courtyard_4k_soft16": ("courtyard", 3840, 2160, "point", 16),
     "city_4k_soft16_wide": ("city", 3840, 2160, "point", 16),  # configs[4] with a five times larger light (SOFT_RADIUS)
+    "city_4k_directional": ("city", 3840, 2160, "directional", 1),   # the reference's own light (RayTracedShadows.cpp:245, comp:128-151) at the headline size
     "calib_4k": ("calib", 3840, 2160, "point", 1),            # counter calibration only (see scenes.calib)
 }
 

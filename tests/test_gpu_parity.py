@@ -86,6 +86,15 @@ def test_config2_city_4k_full_size(ctx, city4k):
     assert 0.2 < want.mean() < 0.8                                                # a real mix of lit / occluded
 
 
+def test_reference_directional_light_city_4k_full_size(ctx, city4k):
+    """The reference's own shader path -- one directional light from the constants block, tmax 1e9 (comp:128-151,
+    RayTracedShadows.cpp:245) -- at the headline size: the default kernel, the plain loop and the packet kernels."""
+    wl = workloads.relight(city4k, "directional")
+    assert wl.light is None                                                       # nothing but RayTracingConstants.lightDirection
+    want = _check_workload(ctx, wl, variants=[-1, 0, 3, 4, 7])
+    assert 0.1 < want.mean() < 0.9
+
+
 def test_config2_courtyard_4k_full_size_hard_scene(ctx):
     """BASELINE configs[2] on the San-Miguel-class stand-in (arcades, nine trees of ~400 000 leaf cards, furniture;
     999 990 triangles): ~60 nodes per ray, rays that scatter between leaves -- packets dissolve, waves run long.
