@@ -413,7 +413,8 @@ static void buildTopSah(uint32_t n, const uint32_t* id, const float* lo, const f
 //   4. stable partition of the two other lists (exclusive sums of the "goes left" flags); the boxes travel with their
 //      list entries, one array per component, so every scan streams coalesced floats (gathering 32-byte boxes by
 //      triangle id, or reading them as float4 pairs 128 B apart per lane, made the scans twice as slow)
-constexpr int SCAN_ITEMS = 4, SCAN_TILE = 256 * SCAN_ITEMS;
+constexpr int SCAN_ITEMS = 4, SCAN_TILE = 256 * SCAN_ITEMS, SCAN_TILE_SHIFT = 10;
+static_assert(SCAN_TILE == 1 << SCAN_TILE_SHIFT, "tile size");
 
 // Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the positions, so the boxes a deep
 // level gathers (few segments per eighth) stay in that XCD's L2.
@@ -442,6 +443,8 @@ struct Sah {
     uint32_t* cnt[3];                               // exclusive sum of side over the list of each axis
     void* boxAggs; uint32_t* cntAggs;               // per-block aggregates of the scans
     uint32_t* flags;                                // [0] a segment with more than one triangle was created, [1] degenerate
+    uint32_t* tileLive; uint32_t* tileLivePrev; uint32_t* tileLiveOut;   // per SCAN_TILE positions: holds a range of more than one
+                                                    // triangle at this level / the previous one / the next one (finished tiles are skipped)
     uint32_t* child; uint32_t* parent; uint32_t* leaves; float* nodeLo; float* nodeHi;
 };
 
@@ -460,6 +463,7 @@ struct BoxOp {
         return Agg{ __shfl_up(v.lo0, d, 64), __shfl_up(v.lo1, d, 64), __shfl_up(v.lo2, d, 64),
                     __shfl_up(v.hi0, d, 64), __shfl_up(v.hi1, d, 64), __shfl_up(v.hi2, d, 64), (uint32_t)__shfl_up((int)v.head, d, 64) };
     }
+    __device__ static bool backward(int y) { return (y & 1) != 0; }
     __device__ static Agg* aggs(const Sah& s) { return (Agg*)s.boxAggs; }
     __device__ static Agg load(const Sah& s, int y, uint32_t t) {
         const uint32_t i = (y & 1) ? s.P - 1 - t : t;
@@ -485,10 +489,20 @@ struct CountOp {
     __device__ static Agg identity() { return 0u; }
     __device__ static Agg combine(Agg a, Agg b) { return a + b; }
     __device__ static Agg shflUp(Agg v, int d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+    __device__ static bool backward(int) { return false; }
     __device__ static Agg* aggs(const Sah& s) { return s.cntAggs; }
     __device__ static Agg load(const Sah& s, int y, uint32_t t) { return s.side[s.ord[y][t]]; }
     __device__ static void store(const Sah& s, int y, uint32_t t, Agg, Agg excl) { s.cnt[y][t] = excl; }
 };
+
+// Does logical tile `blk` of scan slice y touch a position tile that still holds an unfinished range?  (Backward slices
+// run over the positions in reverse: their tile straddles two position tiles.)
+__device__ __forceinline__ bool scanTileLive(const Sah& s, int y, uint32_t blk, bool backward) {
+    if (!backward) return s.tileLive[blk] != 0;
+    const uint32_t hi = s.P - 1 - blk * SCAN_TILE;                       // first logical item = highest position
+    const uint32_t lo = hi >= (uint32_t)SCAN_TILE - 1 ? hi - (SCAN_TILE - 1) : 0u;
+    return (s.tileLive[hi >> SCAN_TILE_SHIFT] | s.tileLive[lo >> SCAN_TILE_SHIFT]) != 0;
+}
 
 // Exclusive prefix of one value per thread over the block (in thread order; the operator need not commute) + the total.
 template <class Op, int WAVES>
@@ -521,6 +535,10 @@ __global__ __launch_bounds__(256) void scanReduceKernel(Sah s, uint32_t nBlocks)
     const int y = blockIdx.y;
     const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
     if (blk >= nBlocks) return;
+    if (!scanTileLive(s, y, blk, Op::backward(y))) {                     // nothing but finished ranges: they neither take nor pass a carry
+        if (threadIdx.x == 0) Op::aggs(s)[(size_t)y * nBlocks + blk] = Op::identity();
+        return;
+    }
     const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     A item[SCAN_ITEMS];
 #pragma unroll
@@ -558,6 +576,7 @@ __global__ __launch_bounds__(256) void scanApplyKernel(Sah s, uint32_t nBlocks) 
     const int y = blockIdx.y;
     const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
     if (blk >= nBlocks) return;
+    if (!scanTileLive(s, y, blk, Op::backward(y))) return;               // (its outputs are never read)
     const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     A incl[SCAN_ITEMS];
 #pragma unroll
@@ -584,6 +603,7 @@ __device__ __forceinline__ int widestAxis(const float* lo, const float* hi) {   
 }
 
 __global__ __launch_bounds__(256) void sahCostKernel(Sah s) {
+    if (!s.tileLive[(blockIdx.x * 256u) >> SCAN_TILE_SHIFT]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long none = ~0ull;
     unsigned long long key = none;
@@ -625,6 +645,7 @@ __global__ __launch_bounds__(256) void sahCostKernel(Sah s) {
 }
 
 __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
+    if (!s.tileLive[(blockIdx.x * 256u) >> SCAN_TILE_SHIFT]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.P) return;
     const uint32_t b = s.segB[i], e = s.segE[i], n = e - b;
@@ -653,6 +674,8 @@ __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
 }
 
 __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
+    const uint32_t tile = (blockIdx.x * 256u) >> SCAN_TILE_SHIFT;
+    if (!s.tileLive[tile] && !s.tileLivePrev[tile]) return;             // finished for two levels: both buffers hold its final state
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t a = blockIdx.y;
     if (i >= s.P) return;
@@ -677,6 +700,7 @@ __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
     if (a == 0) {
         s.posAxisOut[i] = axis;
         if (i < b + m) { s.segBOut[i] = b; s.segEOut[i] = b + m; } else { s.segBOut[i] = b + m; s.segEOut[i] = e; }
+        if ((i < b + m ? m : n - m) > 1) s.tileLiveOut[i >> SCAN_TILE_SHIFT] = 1;
         if (i == b) { s.bestKey[b] = ~0ull; s.bestKey[b + m] = ~0ull; }
     }
 }
@@ -859,6 +883,10 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         LB_HIP(arena.get(&s.splitInfo, (size_t)P * 4)); LB_HIP(arena.get(&s.segParent, (size_t)P * 4)); LB_HIP(arena.get(&s.posAxis, (size_t)P * 4)); LB_HIP(arena.get(&s.posAxisOut, (size_t)P * 4)); LB_HIP(arena.get(&s.side, (size_t)P * 4));
         LB_HIP(arena.get(&s.boxAggs, (size_t)nBlocks * 7 * sizeof(BoxAgg))); LB_HIP(arena.get(&s.cntAggs, (size_t)nBlocks * 3 * 4));
         LB_HIP(arena.get(&s.flags, 16));
+        LB_HIP(arena.get(&s.tileLive, (size_t)nBlocks * 4)); LB_HIP(arena.get(&s.tileLivePrev, (size_t)nBlocks * 4));
+        LB_HIP(arena.get(&s.tileLiveOut, (size_t)nBlocks * 4));
+        LB_HIP(hipMemsetD32Async((hipDeviceptr_t)s.tileLive, 1, nBlocks, nullptr));
+        LB_HIP(hipMemsetD32Async((hipDeviceptr_t)s.tileLivePrev, 1, nBlocks, nullptr));
         size_t tempBytes = 0;
         LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keys32, keysAlt32, identity, s.ord[0], (int)P, 0, 32, nullptr));
         void* temp;
@@ -883,6 +911,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             LB_HIP(hipMemcpy(f, s.flags, 8, hipMemcpyDeviceToHost));
             if (f[1]) { arena.release(); return RTS_ERR_DEGENERATE; }
             if (!f[0]) break;                                           // every child made by this level is a leaf
+            LB_HIP(hipMemsetAsync(s.tileLiveOut, 0, (size_t)nBlocks * 4, nullptr));
             hipLaunchKernelGGL(scanReduceKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<CountOp>, dim3(3), dim3(1024), 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanApplyKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
@@ -892,6 +921,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
                 for (int k = 0; k < 6; ++k) std::swap(s.bc[a][k], s.bcOut[a][k]);
             }
             std::swap(s.segB, s.segBOut); std::swap(s.segE, s.segEOut); std::swap(s.posAxis, s.posAxisOut);
+            { uint32_t* t = s.tileLivePrev; s.tileLivePrev = s.tileLive; s.tileLive = s.tileLiveOut; s.tileLiveOut = t; }
         }
         hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, identity, (uint32_t*)d_packed);
     } else if (P > 1) {
