@@ -654,7 +654,9 @@ __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
     uint32_t axis, m;
     if (key != ~0ull) { axis = (uint32_t)(key >> 30) & 3u; m = (uint32_t)key & 0x3FFFFFFFu; }
     else if (n > s.limit) { axis = (uint32_t)widestAxis(s.segLo + (size_t)b * 3, s.segHi + (size_t)b * 3); m = n - 1; }   // cpp:178
-    else { s.flags[1] = 1; return; }                                     // no finite cost: the reference would not terminate (E-4/E-5)
+    else { s.flags[1] = 1; axis = 0; m = 1; }                            // no finite cost: the reference would not terminate (E-4/E-5);
+                                                                         // the host gives up at its next look at the flags, until then
+                                                                         // this range is split like any other (every index stays valid)
     const uint32_t prim = s.ord[axis][i];
     s.side[prim] = (i - b) < m ? 1u : 0u;
     if (i != b) return;
@@ -899,18 +901,25 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         hipLaunchKernelGGL(sahListBoxesKernel, dim3(gridP.x, 4), block, 0, nullptr, s);
         const uint32_t scanGrid = (nBlocks + 7) / 8 * 8;               // (xcdContiguousBlock)
         const dim3 gridBox(scanGrid, 7), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
+        // The host looks at the flags (a round trip that drains the queue) only where the tree can end: not before level
+        // ceil(log2 P) - 1, then every third level; a level past the end finds every tile finished and does nothing.
+        uint32_t firstLook = 0;
+        while ((1ull << (firstLook + 1)) < (unsigned long long)P) ++firstLook;
+        LB_HIP(hipMemsetAsync(s.flags, 0, 16, nullptr));
         for (uint32_t level = 0;; ++level) {
             if (level > 262144u) { arena.release(); return RTS_ERR_DEGENERATE; }     // (a chain of equal boxes: a level each, ~0.1 ms)
-            LB_HIP(hipMemsetAsync(s.flags, 0, 16, nullptr));
+            LB_HIP(hipMemsetAsync(s.flags, 0, 4, nullptr));             // [0]: this level made a range of more than one triangle
             hipLaunchKernelGGL(scanReduceKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<BoxOp>, dim3(7), dim3(1024), 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanApplyKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(sahCostKernel, gridP, block, 0, nullptr, s);
             hipLaunchKernelGGL(sahSplitKernel, gridP, block, 0, nullptr, s);
-            uint32_t f[2] = { 0, 0 };
-            LB_HIP(hipMemcpy(f, s.flags, 8, hipMemcpyDeviceToHost));
-            if (f[1]) { arena.release(); return RTS_ERR_DEGENERATE; }
-            if (!f[0]) break;                                           // every child made by this level is a leaf
+            if (level >= firstLook && (level - firstLook) % 3 == 0) {
+                uint32_t f[2] = { 0, 0 };
+                LB_HIP(hipMemcpy(f, s.flags, 8, hipMemcpyDeviceToHost));
+                if (f[1]) { arena.release(); return RTS_ERR_DEGENERATE; }
+                if (!f[0]) break;                                       // every child made by this level is a leaf
+            }
             LB_HIP(hipMemsetAsync(s.tileLiveOut, 0, (size_t)nBlocks * 4, nullptr));
             hipLaunchKernelGGL(scanReduceKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<CountOp>, dim3(3), dim3(1024), 0, nullptr, s, nBlocks);
