@@ -452,7 +452,7 @@ struct BoxAgg { float lo0, lo1, lo2, hi0, hi1, hi2; uint32_t head; };   // head:
 
 struct BoxOp {
     typedef BoxAgg Agg;
-    // blockIdx.y = axis * 2 + (0 forward | 1 backward); 6 = forward in the slot order of the reference (node boxes)
+    // aggregate slices: axis * 2 + (0 forward | 1 backward); 6 = forward in the slot order of the reference (node boxes)
     __device__ static Agg identity() { const float inf = __builtin_inff(); return Agg{ inf, inf, inf, -inf, -inf, -inf, 0u }; }
     __device__ static Agg combine(const Agg& a, const Agg& b) {
         if (b.head) return b;
@@ -463,25 +463,11 @@ struct BoxOp {
         return Agg{ __shfl_up(v.lo0, d, 64), __shfl_up(v.lo1, d, 64), __shfl_up(v.lo2, d, 64),
                     __shfl_up(v.hi0, d, 64), __shfl_up(v.hi1, d, 64), __shfl_up(v.hi2, d, 64), (uint32_t)__shfl_up((int)v.head, d, 64) };
     }
-    __device__ static bool backward(int y) { return (y & 1) != 0; }
+    __device__ static Agg shflDown(const Agg& v, int d) {
+        return Agg{ __shfl_down(v.lo0, d, 64), __shfl_down(v.lo1, d, 64), __shfl_down(v.lo2, d, 64),
+                    __shfl_down(v.hi0, d, 64), __shfl_down(v.hi1, d, 64), __shfl_down(v.hi2, d, 64), (uint32_t)__shfl_down((int)v.head, d, 64) };
+    }
     __device__ static Agg* aggs(const Sah& s) { return (Agg*)s.boxAggs; }
-    __device__ static Agg load(const Sah& s, int y, uint32_t t) {
-        const uint32_t i = (y & 1) ? s.P - 1 - t : t;
-        const uint32_t axis = y < 6 ? (uint32_t)y >> 1 : s.posAxis[i];
-        float* const* src = s.bc[axis];
-        const uint32_t head = (y & 1) ? (i + 1 == s.segE[i]) : (i == s.segB[i]);
-        return Agg{ src[0][i], src[1][i], src[2][i], src[3][i], src[4][i], src[5][i], head };
-    }
-    __device__ static void store(const Sah& s, int y, uint32_t t, const Agg& incl, const Agg&) {
-        const uint32_t i = (y & 1) ? s.P - 1 - t : t;
-        const float lo[3] = { incl.lo0, incl.lo1, incl.lo2 }, hi[3] = { incl.hi0, incl.hi1, incl.hi2 };
-        if (y < 6) {
-            ((y & 1) ? s.saR[y >> 1] : s.saL[y >> 1])[i] = surfaceArea(lo, hi);
-        } else if (i + 1 == s.segE[i]) {                               // the whole segment: its box is the node's (cpp:190)
-            const uint32_t b = s.segB[i];
-            for (int a = 0; a < 3; ++a) { s.segLo[(size_t)b * 3 + a] = lo[a]; s.segHi[(size_t)b * 3 + a] = hi[a]; }
-        }
-    }
 };
 
 struct CountOp {
@@ -489,20 +475,10 @@ struct CountOp {
     __device__ static Agg identity() { return 0u; }
     __device__ static Agg combine(Agg a, Agg b) { return a + b; }
     __device__ static Agg shflUp(Agg v, int d) { return (uint32_t)__shfl_up((int)v, d, 64); }
-    __device__ static bool backward(int) { return false; }
     __device__ static Agg* aggs(const Sah& s) { return s.cntAggs; }
     __device__ static Agg load(const Sah& s, int y, uint32_t t) { return s.side[s.ord[y][t]]; }
     __device__ static void store(const Sah& s, int y, uint32_t t, Agg, Agg excl) { s.cnt[y][t] = excl; }
 };
-
-// Does logical tile `blk` of scan slice y touch a position tile that still holds an unfinished range?  (Backward slices
-// run over the positions in reverse: their tile straddles two position tiles.)
-__device__ __forceinline__ bool scanTileLive(const Sah& s, int y, uint32_t blk, bool backward) {
-    if (!backward) return s.tileLive[blk] != 0;
-    const uint32_t hi = s.P - 1 - blk * SCAN_TILE;                       // first logical item = highest position
-    const uint32_t lo = hi >= (uint32_t)SCAN_TILE - 1 ? hi - (SCAN_TILE - 1) : 0u;
-    return (s.tileLive[hi >> SCAN_TILE_SHIFT] | s.tileLive[lo >> SCAN_TILE_SHIFT]) != 0;
-}
 
 // Exclusive prefix of one value per thread over the block (in thread order; the operator need not commute) + the total.
 template <class Op, int WAVES>
@@ -528,6 +504,134 @@ __device__ __forceinline__ void blockExclusive(const typename Op::Agg& mine, typ
     __syncthreads();
 }
 
+// The same in the opposite thread order (the backward scans): thread t + 1 comes before thread t.
+template <class Op, int WAVES>
+__device__ __forceinline__ void blockExclusiveRev(const typename Op::Agg& mine, typename Op::Agg* excl, typename Op::Agg* total,
+                                                  typename Op::Agg* lds) {
+    typedef typename Op::Agg A;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    A x = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const A o = Op::shflDown(x, d);
+        if (lane + d < 64) x = Op::combine(o, x);
+    }
+    if (lane == 0) lds[wave] = x;
+    __syncthreads();
+    const A prev = Op::shflDown(x, 1);
+    A pre = Op::identity(), tot = Op::identity();
+    for (int w = WAVES - 1; w >= 0; --w) {
+        if (w == wave) pre = tot;
+        tot = Op::combine(tot, lds[w]);
+    }
+    *excl = lane == 63 ? pre : Op::combine(pre, prev);
+    *total = tot;
+    __syncthreads();
+}
+
+// Box scans, fused: blockIdx.y = 0..2 runs the forward AND the backward scan of that axis' list from one load of the tile
+// (slices 2z and 2z + 1 of the aggregates; the backward slice is indexed from the last tile down, so the same
+// scanBlocksKernel serves it), blockIdx.y = 3 the forward scan in the reference's slot order (slice 6, node boxes).
+struct BoxTile {
+    float c[SCAN_ITEMS][6];
+    uint32_t b[SCAN_ITEMS], e[SCAN_ITEMS];
+};
+
+__device__ __forceinline__ void loadBoxTile(const Sah& s, uint32_t z, uint32_t base, BoxTile* t) {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {                               // clamped, no branch: every load is in flight at once
+        const uint32_t i = base + j < s.P ? base + j : s.P - 1;
+        const uint32_t axis = z < 3 ? z : s.posAxis[i];
+        float* const* src = s.bc[axis];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t->c[j][k] = src[k][i];
+        t->b[j] = s.segB[i]; t->e[j] = s.segE[i];
+    }
+}
+
+__device__ __forceinline__ BoxAgg tileItem(const BoxTile& t, int j, bool head) {
+    return BoxAgg{ t.c[j][0], t.c[j][1], t.c[j][2], t.c[j][3], t.c[j][4], t.c[j][5], head ? 1u : 0u };
+}
+
+__device__ __forceinline__ float aggArea(const BoxAgg& a) {
+    const float lo[3] = { a.lo0, a.lo1, a.lo2 }, hi[3] = { a.hi0, a.hi1, a.hi2 };
+    return surfaceArea(lo, hi);
+}
+
+__global__ __launch_bounds__(256) void boxReduceFusedKernel(Sah s, uint32_t nBlocks) {
+    __shared__ BoxAgg lds[4];
+    const uint32_t z = blockIdx.y;
+    const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
+    if (blk >= nBlocks) return;
+    BoxAgg* aggs = (BoxAgg*)s.boxAggs;
+    const size_t fIdx = (size_t)(z < 3 ? 2 * z : 6) * nBlocks + blk, bIdx = (size_t)(2 * z + 1) * nBlocks + (nBlocks - 1 - blk);
+    if (!s.tileLive[blk]) {                                              // nothing but finished ranges: they neither take nor pass a carry
+        if (threadIdx.x == 0) { aggs[fIdx] = BoxOp::identity(); if (z < 3) aggs[bIdx] = BoxOp::identity(); }
+        return;
+    }
+    const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    BoxTile t;
+    loadBoxTile(s, z, base, &t);
+    BoxAgg acc = BoxOp::identity(), excl, tot;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < s.P) acc = BoxOp::combine(acc, tileItem(t, j, base + j == t.b[j]));
+    blockExclusive<BoxOp, 4>(acc, &excl, &tot, lds);
+    if (threadIdx.x == 0) aggs[fIdx] = tot;
+    if (z == 3) return;
+    acc = BoxOp::identity();
+#pragma unroll
+    for (int j = SCAN_ITEMS - 1; j >= 0; --j)
+        if (base + j < s.P) acc = BoxOp::combine(acc, tileItem(t, j, base + j + 1 == t.e[j]));
+    blockExclusiveRev<BoxOp, 4>(acc, &excl, &tot, lds);
+    if (threadIdx.x == 0) aggs[bIdx] = tot;
+}
+
+__global__ __launch_bounds__(256) void boxApplyFusedKernel(Sah s, uint32_t nBlocks) {
+    __shared__ BoxAgg lds[4];
+    const uint32_t z = blockIdx.y;
+    const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
+    if (blk >= nBlocks) return;
+    if (!s.tileLive[blk]) return;                                        // (its outputs are never read)
+    const BoxAgg* aggs = (const BoxAgg*)s.boxAggs;
+    const size_t fIdx = (size_t)(z < 3 ? 2 * z : 6) * nBlocks + blk, bIdx = (size_t)(2 * z + 1) * nBlocks + (nBlocks - 1 - blk);
+    const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    BoxTile t;
+    loadBoxTile(s, z, base, &t);
+    BoxAgg incl[SCAN_ITEMS], acc = BoxOp::identity(), excl, tot;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < s.P) acc = BoxOp::combine(acc, tileItem(t, j, base + j == t.b[j]));
+        incl[j] = acc;
+    }
+    blockExclusive<BoxOp, 4>(acc, &excl, &tot, lds);
+    BoxAgg pre = BoxOp::combine(aggs[fIdx], excl);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const uint32_t i = base + j;
+        if (i >= s.P) continue;
+        const BoxAgg full = BoxOp::combine(pre, incl[j]);
+        if (z < 3) {
+            s.saL[z][i] = aggArea(full);
+        } else if (i + 1 == t.e[j]) {                                    // the whole range: its box is the node's (cpp:190)
+            const uint32_t b = t.b[j];
+            s.segLo[(size_t)b * 3] = full.lo0; s.segLo[(size_t)b * 3 + 1] = full.lo1; s.segLo[(size_t)b * 3 + 2] = full.lo2;
+            s.segHi[(size_t)b * 3] = full.hi0; s.segHi[(size_t)b * 3 + 1] = full.hi1; s.segHi[(size_t)b * 3 + 2] = full.hi2;
+        }
+    }
+    if (z == 3) return;
+    acc = BoxOp::identity();
+#pragma unroll
+    for (int j = SCAN_ITEMS - 1; j >= 0; --j) {
+        if (base + j < s.P) acc = BoxOp::combine(acc, tileItem(t, j, base + j + 1 == t.e[j]));
+        incl[j] = acc;
+    }
+    blockExclusiveRev<BoxOp, 4>(acc, &excl, &tot, lds);
+    pre = BoxOp::combine(aggs[bIdx], excl);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < s.P) s.saR[z][base + j] = aggArea(BoxOp::combine(pre, incl[j]));
+}
+
 template <class Op>
 __global__ __launch_bounds__(256) void scanReduceKernel(Sah s, uint32_t nBlocks) {
     typedef typename Op::Agg A;
@@ -535,7 +639,7 @@ __global__ __launch_bounds__(256) void scanReduceKernel(Sah s, uint32_t nBlocks)
     const int y = blockIdx.y;
     const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
     if (blk >= nBlocks) return;
-    if (!scanTileLive(s, y, blk, Op::backward(y))) {                     // nothing but finished ranges: they neither take nor pass a carry
+    if (!s.tileLive[blk]) {                                              // nothing but finished ranges: their sum is never read
         if (threadIdx.x == 0) Op::aggs(s)[(size_t)y * nBlocks + blk] = Op::identity();
         return;
     }
@@ -576,7 +680,7 @@ __global__ __launch_bounds__(256) void scanApplyKernel(Sah s, uint32_t nBlocks) 
     const int y = blockIdx.y;
     const uint32_t blk = xcdContiguousBlock(blockIdx.x, nBlocks);
     if (blk >= nBlocks) return;
-    if (!scanTileLive(s, y, blk, Op::backward(y))) return;               // (its outputs are never read)
+    if (!s.tileLive[blk]) return;                                        // (its outputs are never read)
     const uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     A incl[SCAN_ITEMS];
 #pragma unroll
@@ -900,7 +1004,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         hipLaunchKernelGGL(sahInitKernel, gridP, block, 0, nullptr, s);
         hipLaunchKernelGGL(sahListBoxesKernel, dim3(gridP.x, 4), block, 0, nullptr, s);
         const uint32_t scanGrid = (nBlocks + 7) / 8 * 8;               // (xcdContiguousBlock)
-        const dim3 gridBox(scanGrid, 7), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
+        const dim3 gridBox(scanGrid, 4), gridCnt(scanGrid, 3), gridScatter(gridP.x, 3);
         // The host looks at the flags (a round trip that drains the queue) only where the tree can end: not before level
         // ceil(log2 P) - 1, then every third level; a level past the end finds every tile finished and does nothing.
         uint32_t firstLook = 0;
@@ -909,9 +1013,9 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         for (uint32_t level = 0;; ++level) {
             if (level > 262144u) { arena.release(); return RTS_ERR_DEGENERATE; }     // (a chain of equal boxes: a level each, ~0.1 ms)
             LB_HIP(hipMemsetAsync(s.flags, 0, 4, nullptr));             // [0]: this level made a range of more than one triangle
-            hipLaunchKernelGGL(scanReduceKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(boxReduceFusedKernel, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<BoxOp>, dim3(7), dim3(1024), 0, nullptr, s, nBlocks);
-            hipLaunchKernelGGL(scanApplyKernel<BoxOp>, gridBox, block, 0, nullptr, s, nBlocks);
+            hipLaunchKernelGGL(boxApplyFusedKernel, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(sahCostKernel, gridP, block, 0, nullptr, s);
             hipLaunchKernelGGL(sahSplitKernel, gridP, block, 0, nullptr, s);
             if (level >= firstLook && (level - firstLook) % 3 == 0) {
