@@ -749,6 +749,7 @@ __global__ __launch_bounds__(256) void sahCostKernel(Sah s) {
 }
 
 __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
+    if ((blockIdx.x & 3u) == 0 && threadIdx.x == 0) s.tileLiveOut[(blockIdx.x * 256u) >> SCAN_TILE_SHIFT] = 0;   // (the scatter of this level sets it)
     if (!s.tileLive[(blockIdx.x * 256u) >> SCAN_TILE_SHIFT]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.P) return;
@@ -780,6 +781,7 @@ __global__ __launch_bounds__(256) void sahSplitKernel(Sah s) {
 }
 
 __global__ __launch_bounds__(256) void sahScatterKernel(Sah s) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) s.flags[0] = 0;     // (the split of the next level sets it)
     const uint32_t tile = (blockIdx.x * 256u) >> SCAN_TILE_SHIFT;
     if (!s.tileLive[tile] && !s.tileLivePrev[tile]) return;             // finished for two levels: both buffers hold its final state
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1012,7 +1014,6 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
         LB_HIP(hipMemsetAsync(s.flags, 0, 16, nullptr));
         for (uint32_t level = 0;; ++level) {
             if (level > 262144u) { arena.release(); return RTS_ERR_DEGENERATE; }     // (a chain of equal boxes: a level each, ~0.1 ms)
-            LB_HIP(hipMemsetAsync(s.flags, 0, 4, nullptr));             // [0]: this level made a range of more than one triangle
             hipLaunchKernelGGL(boxReduceFusedKernel, gridBox, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<BoxOp>, dim3(7), dim3(1024), 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(boxApplyFusedKernel, gridBox, block, 0, nullptr, s, nBlocks);
@@ -1024,7 +1025,6 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
                 if (f[1]) { arena.release(); return RTS_ERR_DEGENERATE; }
                 if (!f[0]) break;                                       // every child made by this level is a leaf
             }
-            LB_HIP(hipMemsetAsync(s.tileLiveOut, 0, (size_t)nBlocks * 4, nullptr));
             hipLaunchKernelGGL(scanReduceKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanBlocksKernel<CountOp>, dim3(3), dim3(1024), 0, nullptr, s, nBlocks);
             hipLaunchKernelGGL(scanApplyKernel<CountOp>, gridCnt, block, 0, nullptr, s, nBlocks);
