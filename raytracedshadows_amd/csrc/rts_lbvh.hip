@@ -416,8 +416,8 @@ static void buildTopSah(uint32_t n, const uint32_t* id, const float* lo, const f
 constexpr int SCAN_ITEMS = 4, SCAN_TILE = 256 * SCAN_ITEMS, SCAN_TILE_SHIFT = 10;
 static_assert(SCAN_TILE == 1 << SCAN_TILE_SHIFT, "tile size");
 
-// Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the positions, so the boxes a deep
-// level gathers (few segments per eighth) stay in that XCD's L2.
+// Workgroups go round-robin over the 8 XCDs: give each XCD one contiguous eighth of the positions, so the second pass of
+// a scan finds the tile its first pass read in the same XCD's L2.
 __device__ __forceinline__ uint32_t xcdContiguousBlock(uint32_t blk, uint32_t nBlocks) {
     const uint32_t per = (nBlocks + 7) / 8, mapped = (blk & 7u) * per + (blk >> 3);
     return mapped;                                                       // may be >= nBlocks: such a block has nothing to do
