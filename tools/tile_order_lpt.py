@@ -8,8 +8,8 @@ from raytracedshadows_amd import api, workloads
 
 def main():
 
-    for cfg in ("atrium_1080p", "city_4k"):
-        wl = workloads.prepare_config(cfg)
+    for cfg in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("atrium_1080p", "city_4k")):
+        wl = workloads.prepare_config(cfg, cache=True)
         W, H = wl.W, wl.H
         with api.ShadowContext(0) as ctx:
             ctx.set_bvh(wl.packed)
@@ -20,12 +20,12 @@ def main():
             waves = bx * by
 
             def timeit(tag):
-                for _ in range(3):
+                for _ in range(400):                                   # (clocks up: a handful of launches is a cold measurement)
                     ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
                 ts = []
-                for _ in range(30):
-                    ctx.timer_begin(); ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light); ctx.timer_end()
-                    ts.append(ctx.timer_elapsed_ms())
+                for _ in range(40):
+                    ctx.timer_mark(0); ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light); ctx.timer_mark(1)
+                    ts.append(ctx.timer_between_ms(0, 1))
                 got = np.zeros((H, W), np.uint8); ctx.d2h(got, d_mask)
                 print(f"[{cfg}] {tag}: {np.median(ts):.4f} ms (min {min(ts):.4f})", flush=True)
                 return got
@@ -49,6 +49,20 @@ def main():
             ctx.set_tile_order(np.argsort(-bucket, kind="stable").astype(np.uint32))
             c = timeit("longest first, log2 buckets")
             assert (c == ref).all()
+            # rows of tiles in the order of their longest tile (natural order inside a row): what a per-row feedback could do
+            rowmax = dur.reshape(by, bx).max(1)
+            rows = np.argsort(-rowmax, kind="stable")
+            ctx.set_tile_order((rows[:, None] * bx + np.arange(bx)[None, :]).reshape(-1).astype(np.uint32))
+            d = timeit("rows by their longest tile, tiles in natural order")
+            assert (d == ref).all()
+            rowsum = dur.reshape(by, bx).sum(1)
+            rows = np.argsort(-rowsum, kind="stable")
+            ctx.set_tile_order((rows[:, None] * bx + np.arange(bx)[None, :]).reshape(-1).astype(np.uint32))
+            e = timeit("rows by their total time, tiles in natural order")
+            assert (e == ref).all()
+            ctx.set_tile_order(np.arange(waves, dtype=np.uint32))
+            f = timeit("natural order through the order table")
+            assert (f == ref).all()
             ctx.set_tile_order(None)
             print(f"[{cfg}] durations: mean {dur.mean():.0f} p50 {np.percentile(dur,50):.0f} p99 {np.percentile(dur,99):.0f} max {dur.max()} cycles; sum/8192 = {dur.sum()/8192:.0f}")
 
