@@ -214,3 +214,31 @@ def test_any_hit_does_not_depend_on_the_child_order():
     stats = [oracle.order_experiment(wl.packed, wl.constants.as_array(), lt, wl.positions, wl.W, wl.H, m) for m in (0, 1, 2)]
     assert all(s["occluded"] == int((want == 0).sum()) for s in stats)
     assert len({round(s["visits_per_ray"], 6) for s in stats}) > 1          # ... while the visit counts do differ
+
+
+def test_ties_by_triangle_id_is_the_same_builder_where_no_centroids_tie():
+    """`ties_by_prim` (the rule the device SAH builder is held to, oracle/rts_oracle.cpp CtrLess) only decides what std::sort leaves open:
+    on a mesh whose centroids differ pairwise on every axis it IS the reference restatement; on a grid full of equal centroids it is
+    another valid stream of the same layout; and -0 == +0 as in the reference's comparison."""
+    rs = np.random.RandomState(8)
+    n = 3000
+    c = np.stack([rs.permutation(n) + 1 for _ in range(3)], 1).astype(np.float64) / 1024.0       # distinct per axis, exactly representable
+    h = rs.randint(1, 4, size=(n, 3)).astype(np.float64) / 4096.0
+    sign = np.array([[-1, -1, -1], [1, 1, -1], [-1, 1, 1]], np.float64)
+    v = (c[:, None, :] + sign[None, :, :] * h[:, None, :]).astype(np.float32).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    for limit in (1000000, 64):
+        assert (oracle.bvh_build(v, 3, idx, n, sah_limit=limit, ties_by_prim=True) == oracle.bvh_build(v, 3, idx, n, sah_limit=limit)).all()
+    sc = scenes.terrain(24)
+    fv, fi = sc.flat()
+    tied = oracle.bvh_build(fv, 8, fi, sc.triangle_count, ties_by_prim=True)
+    _invariants(tied, sc.triangle_count)
+    assert api.bvh_validate(tied) == sc.triangle_count
+    t0 = np.array([[0.0, 0, 0], [0.0, 1, 0], [0.0, 0, 1]], np.float32)
+    t1 = t0 + np.float32([0, 0.5, 0])
+    t1[:, 0] = np.float32(-0.0)
+    z = np.concatenate([t0, t1, t1 + np.float32([0, 10, 0]), t0 + np.float32([0, 10, 0])])
+    z[6:9, 0] = np.float32(-0.0)
+    packed = oracle.bvh_build(z, 3, np.arange(12, dtype=np.uint32), 4, ties_by_prim=True)
+    leaves = [int(x) - 14 for x in packed[0:14:2, 3] if x != 0xFFFFFFFF]
+    assert leaves == [0, 1, 2, 3]                       # x centroids +0, -0, -0, +0 compare equal: triangle order decides
