@@ -1,5 +1,6 @@
 """Soak (GPU box): random large frames (packet kernels at full occupancy) on terrain / atrium / cornell / courtyard scenes with random
-cameras, lights, sample counts, tuning knobs and stripe layouts, each mask against the oracle, for a fixed time."""
+cameras, lights, sample counts, tuning knobs, stripe layouts and producers of the stream (the host builder or one of the four GPU
+builders), each mask against the oracle on the same stream, for a fixed time."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +18,11 @@ with api.ShadowContext(0) as ctx:
         sc = scenes.terrain(int(rs.choice([40, 90, 160]))) if kind < 3 else (scenes.cornell() if kind < 5 else
                                                                               scenes.SCENES["atrium"]() if kind < 7 else scenes.courtyard())
         verts, idx = sc.flat()
-        packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes
+        producer = str(rs.choice(["host", "host", "sah", "ploc", "lbvh", "ploc_sah"]))
+        if producer == "host":
+            packed = api.BVHBuilder().build(verts, 8, idx, sc.triangle_count).m_packedNodes
+        else:
+            packed, _ = api.bvh_build_device(ctx, verts, 8, idx, sc.triangle_count, algorithm=producer)
         lo, hi = sc.bbox_min, sc.bbox_max
         W, H = int(rs.randint(520, 1500)), int(rs.randint(500, 900))
         eye = (hi + (hi - lo) * rs.random_sample(3) * 0.5 + 1).astype(np.float32)
@@ -53,7 +58,7 @@ with api.ShadowContext(0) as ctx:
                 ctx.synchronize()
                 ctx.d2h(got, d_mask)
                 bad = int((got != want).sum())
-                assert bad == 0, (cases, sc.name, W, H, kernel, spp, n, bad)
+                assert bad == 0, (cases, sc.name, producer, W, H, kernel, spp, n, bad)
         finally:
             ctx.free(d_pos); ctx.free(d_mask)
             for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0)):
@@ -61,4 +66,4 @@ with api.ShadowContext(0) as ctx:
         cases += 1
         if cases % 5 == 0:
             print(f"{cases} big cases ok ({time.time() - t0:.0f}s)", flush=True)
-print(f"soak_big: {cases} random large frames x 6 kernels (random knobs, stripes, 1-16 samples) all bit-exact ({time.time() - t0:.0f}s)")
+print(f"soak_big: {cases} random large frames x 6 kernels (random knobs, stripes, 1-16 samples, host- and GPU-built streams) all bit-exact ({time.time() - t0:.0f}s)")
