@@ -35,6 +35,7 @@ struct rts_ctx {
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
+    void* d_scratch = nullptr; size_t scratchBytes = 0;    // working memory of the GPU builders, kept between builds
 };
 
 namespace {
@@ -152,6 +153,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_waveStats) (void)hipFree(c->d_waveStats);
     if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -434,6 +436,19 @@ int rts_timer_between_ms(rts_ctx* c, uint32_t a, uint32_t b, float* ms) {
 const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel : ""; }
 
 int rts_ctx_device_ordinal(rts_ctx* c) { return c ? c->device : 0; }
+
+// used by the GPU builders (rts_lbvh.hip): one buffer the context keeps between builds (a rebuild per frame pays no
+// hipMalloc / hipFree: fifty of them cost more than the build).  NULL if it cannot be had; the caller then allocates.
+void* rts_ctx_scratch(rts_ctx* c, size_t bytes) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (bytes > c->scratchBytes) {
+        if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratchBytes = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        c->d_scratch = p; c->scratchBytes = bytes;
+    }
+    return c->d_scratch;
+}
 
 // used by the GPU builder (rts_lbvh.hip): the context takes ownership of a packed stream that is already on the
 // device (finite vertices were checked there; LBVH boxes are min <= max by construction)

@@ -30,6 +30,7 @@
 
 extern "C" int rts_ctx_adopt_device_bvh(rts_ctx* ctx, void* d_packed, size_t count_vec4, uint32_t prim_count);  // rts_api.cpp
 extern "C" int rts_ctx_device_ordinal(rts_ctx* ctx);
+extern "C" void* rts_ctx_scratch(rts_ctx* ctx, size_t bytes);
 
 namespace {
 
@@ -894,18 +895,26 @@ __global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P 
     packed[8] = __float_as_uint(v0[0]); packed[9] = __float_as_uint(v0[1]); packed[10] = __float_as_uint(v0[2]); packed[11] = 0;
 }
 
-struct DeviceArena {            // frees everything it handed out, whatever path leaves the function
-    void* ptrs[96]; int n = 0;
+struct DeviceArena {            // working buffers: carved out of the context's scratch buffer; what does not fit (and what
+    char* slab = nullptr;       // must outlive the build) is a hipMalloc of its own, freed whatever path leaves the function
+    size_t slabBytes = 0, used = 0;
+    void* own[16]; int nOwn = 0;
     hipEvent_t ev[2] = { nullptr, nullptr };
-    template <typename T> hipError_t get(T** p, size_t bytes) {
+    template <typename T> hipError_t getOwn(T** p, size_t bytes) {
+        if (nOwn == 16) return hipErrorOutOfMemory;
         void* v = nullptr;
         hipError_t e = hipMalloc(&v, bytes ? bytes : 16);
-        if (e == hipSuccess) { ptrs[n++] = v; *p = (T*)v; }
+        if (e == hipSuccess) { own[nOwn++] = v; *p = (T*)v; }
         return e;
     }
+    template <typename T> hipError_t get(T** p, size_t bytes) {
+        const size_t aligned = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+        if (slab && used + aligned <= slabBytes) { *p = (T*)(slab + used); used += aligned; return hipSuccess; }
+        return getOwn(p, bytes);
+    }
     void release(void* keep = nullptr) {
-        for (int i = 0; i < n; ++i) if (ptrs[i] != keep) (void)hipFree(ptrs[i]);
-        n = 0;
+        for (int i = 0; i < nOwn; ++i) if (own[i] != keep) (void)hipFree(own[i]);
+        nOwn = 0;
         for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
 };
@@ -930,13 +939,16 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     if (e0 != hipSuccess) return RTS_ERR_HIP + (int)e0;
 
     DeviceArena arena;
+    arena.slabBytes = vertex_floats * 4 + (size_t)P * 600 + ((size_t)4 << 20);     // every buffer of the largest path (SAH) + sort scratch
+    arena.slab = (char*)rts_ctx_scratch(ctx, arena.slabBytes);
+    if (!arena.slab) arena.slabBytes = 0;
     Lbvh b{};
     b.P = P; b.stride = stride;
     float* d_verts; uint32_t* d_idx; uint32_t* d_packed;
     uint64_t* keysAlt; uint32_t* orderAlt;
     LB_HIP(arena.get(&d_verts, vertex_floats * 4));
     LB_HIP(arena.get(&d_idx, (size_t)P * 12));
-    LB_HIP(arena.get(&d_packed, count * 16 + 64));
+    LB_HIP(arena.getOwn(&d_packed, count * 16 + 64));                   // (may become the context's BVH)
     LB_HIP(arena.get(&b.leafLo, (size_t)P * 12)); LB_HIP(arena.get(&b.leafHi, (size_t)P * 12));
     LB_HIP(arena.get(&b.sceneBox, 32));
     LB_HIP(arena.get(&b.keys, (size_t)P * 8)); LB_HIP(arena.get(&keysAlt, (size_t)P * 8));
