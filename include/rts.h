@@ -120,7 +120,9 @@ int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_
  *                       without such ties the stream is byte-identical to rts_bvh_build's, otherwise a tree of the
  *                       same quality.  RTS_ERR_DEGENERATE where the reference would not terminate.
  * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
- * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build. */
+ * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build.
+ * The builders' working memory (about 0.6 KB per triangle) stays with the context until rts_ctx_destroy, so that a rebuild
+ * per frame allocates nothing. */
 enum { RTS_GPU_BUILD_LBVH = 0, RTS_GPU_BUILD_PLOC = 1, RTS_GPU_BUILD_PLOC_SAH = 2, RTS_GPU_BUILD_SAH = 3 };
 int rts_bvh_build_device(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride_floats,
                          const uint32_t* indices, uint32_t prim_count, rts_vec4u* out_packed,
