@@ -119,7 +119,8 @@ int rts_bvh_validate(const rts_vec4u* packed, size_t count_vec4, uint32_t* prim_
  *                       ordered by triangle id where the reference's std::sort leaves them unspecified: on a mesh
  *                       without such ties the stream is byte-identical to rts_bvh_build's, otherwise a tree of the
  *                       same quality.  RTS_ERR_DEGENERATE where the reference would not terminate.
- * vertex_floats = number of floats in `vertices`.  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
+ * vertex_floats = number of floats in `vertices`.  `vertices` and `indices` may be host pointers (copied to the device) or
+ * device pointers on the context's device (used where they lie: a renderer's vertex and index buffers).  out_packed (host, nullable) receives the 5P-2 vec4; install != 0
  * makes the stream the context's BVH without a host round trip.  build_ms (nullable): device time of the build.
  * The builders' working memory (about 0.6 KB per triangle) stays with the context until rts_ctx_destroy, so that a rebuild
  * per frame allocates nothing. */

@@ -225,14 +225,23 @@ def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, 
     -- ``radius`` is then the range size above which the median split is used, 0 = the reference's 1 000 000.  Over the
     Morton order: "ploc" (locally-ordered clustering, ``radius`` neighbours each way, 0 = 16), "lbvh" (Karras hierarchy),
     "ploc_sah" (PLOC below 65 536 clusters, full-sweep SAH over the clusters on the host above).
-    Returns (packed or None, device milliseconds)."""
-    vertices = np.ascontiguousarray(vertices, dtype=np.float32)
-    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    ``vertices`` may be ``(device pointer, number of floats)`` and ``indices`` a device pointer: geometry that already lives on
+    the context's device is used in place.  Returns (packed or None, device milliseconds)."""
+    if isinstance(vertices, tuple):                  # (device pointer, number of floats): geometry already on the device
+        v_ptr, v_floats = C.c_void_p(vertices[0]), int(vertices[1])
+    else:
+        vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+        v_ptr, v_floats = _ptr(vertices), vertices.size
+    if isinstance(indices, int):
+        i_ptr = C.c_void_p(indices)
+    else:
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        i_ptr = _ptr(indices)
     n = packed_count(prim_count)
     packed = np.zeros((max(n, 1), 4), dtype=np.uint32) if want_packed else None
     ms = C.c_float(0)
     algo = {"lbvh": 0, "ploc": 1, "ploc_sah": 2, "sah": 3}[algorithm]
-    _check(_lib.rts_bvh_build_device_ex(ctx.handle, _ptr(vertices), vertices.size, stride, _ptr(indices), prim_count,
+    _check(_lib.rts_bvh_build_device_ex(ctx.handle, v_ptr, v_floats, stride, i_ptr, prim_count,
                                         algo, radius, _ptr(packed) if want_packed else None, n if want_packed else 0,
                                         int(install), C.byref(ms)), "rts_bvh_build_device_ex")
     return (packed[:n] if want_packed else None), float(ms.value)

@@ -895,6 +895,18 @@ __global__ void emitSingleKernel(Lbvh b, uint32_t* packed) {               // P 
     packed[8] = __float_as_uint(v0[0]); packed[9] = __float_as_uint(v0[1]); packed[10] = __float_as_uint(v0[2]); packed[11] = 0;
 }
 
+__global__ void checkIndicesKernel(const uint32_t* idx, uint32_t n, uint32_t stride, size_t vertexFloats, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (size_t)idx[i] * stride + 3 > vertexFloats) flags[1] = 1;
+}
+
+// ordinal of the device a pointer's memory lives on, -1 for host memory (pageable, pinned or managed: those are copied)
+int deviceOf(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
 struct DeviceArena {            // working buffers: carved out of the context's scratch buffer; what does not fit (and what
     char* slab = nullptr;       // must outlive the build) is a hipMalloc of its own, freed whatever path leaves the function
     size_t slabBytes = 0, used = 0;
@@ -933,10 +945,14 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     if (radius == 0) radius = algorithm == RTS_GPU_BUILD_SAH ? 1000000u : 16u;      // (SAH: BVHBuilder.cpp:83)
     const size_t count = (size_t)5 * P - 2;
     if (out_packed && out_cap < count) return RTS_ERR_CAPACITY;
-    for (size_t i = 0; i < (size_t)3 * P; ++i)
-        if ((size_t)indices[i] * stride + 3 > vertex_floats) return RTS_ERR_INVALID_ARG;
     hipError_t e0 = hipSetDevice(rts_ctx_device_ordinal(ctx));
     if (e0 != hipSuccess) return RTS_ERR_HIP + (int)e0;
+    // geometry that already lives on the context's device is used where it lies (no copy; its indices are checked by a kernel)
+    const int vertsOn = deviceOf(vertices), idxOn = deviceOf(indices);
+    if ((vertsOn >= 0 && vertsOn != rts_ctx_device_ordinal(ctx)) || (idxOn >= 0 && idxOn != rts_ctx_device_ordinal(ctx))) return RTS_ERR_INVALID_ARG;
+    if (idxOn < 0)
+        for (size_t i = 0; i < (size_t)3 * P; ++i)
+            if ((size_t)indices[i] * stride + 3 > vertex_floats) return RTS_ERR_INVALID_ARG;
 
     DeviceArena arena;
     arena.slabBytes = vertex_floats * 4 + (size_t)P * 600 + ((size_t)4 << 20);     // every buffer of the largest path (SAH) + sort scratch
@@ -946,8 +962,8 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     b.P = P; b.stride = stride;
     float* d_verts; uint32_t* d_idx; uint32_t* d_packed;
     uint64_t* keysAlt; uint32_t* orderAlt;
-    LB_HIP(arena.get(&d_verts, vertex_floats * 4));
-    LB_HIP(arena.get(&d_idx, (size_t)P * 12));
+    if (vertsOn >= 0) d_verts = const_cast<float*>(vertices); else LB_HIP(arena.get(&d_verts, vertex_floats * 4));
+    if (idxOn >= 0) d_idx = const_cast<uint32_t*>(indices); else LB_HIP(arena.get(&d_idx, (size_t)P * 12));
     LB_HIP(arena.getOwn(&d_packed, count * 16 + 64));                   // (may become the context's BVH)
     LB_HIP(arena.get(&b.leafLo, (size_t)P * 12)); LB_HIP(arena.get(&b.leafHi, (size_t)P * 12));
     LB_HIP(arena.get(&b.sceneBox, 32));
@@ -959,8 +975,8 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     LB_HIP(arena.get(&b.pending, 16)); LB_HIP(arena.get(&b.flags, 16));
     b.verts = d_verts; b.indices = d_idx;
 
-    LB_HIP(hipMemcpy(d_verts, vertices, vertex_floats * 4, hipMemcpyHostToDevice));
-    LB_HIP(hipMemcpy(d_idx, indices, (size_t)P * 12, hipMemcpyHostToDevice));
+    if (vertsOn < 0) LB_HIP(hipMemcpy(d_verts, vertices, vertex_floats * 4, hipMemcpyHostToDevice));
+    if (idxOn < 0) LB_HIP(hipMemcpy(d_idx, indices, (size_t)P * 12, hipMemcpyHostToDevice));
     LB_HIP(hipEventCreate(&arena.ev[0])); LB_HIP(hipEventCreate(&arena.ev[1]));
     const hipEvent_t ev0 = arena.ev[0], ev1 = arena.ev[1];
     LB_HIP(hipEventRecord(ev0, nullptr));
@@ -972,6 +988,12 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     const uint32_t pend = P - 1;
     LB_HIP(hipMemcpy(b.pending, &pend, 4, hipMemcpyHostToDevice));
     const dim3 block(256), gridP((P + 255) / 256), gridN((2 * P - 1 + 255) / 256);
+    if (idxOn >= 0) {
+        hipLaunchKernelGGL(checkIndicesKernel, dim3((3 * P + 255) / 256), block, 0, nullptr, d_idx, 3 * P, stride, vertex_floats, b.flags);
+        uint32_t bad = 0;
+        LB_HIP(hipMemcpy(&bad, b.flags + 1, 4, hipMemcpyDeviceToHost));
+        if (bad) { arena.release(); return RTS_ERR_INVALID_ARG; }
+    }
     hipLaunchKernelGGL(leafBoxesKernel, gridP, block, 0, nullptr, b);
     uint32_t flag = 0;
     LB_HIP(hipMemcpy(&flag, b.flags, 4, hipMemcpyDeviceToHost));

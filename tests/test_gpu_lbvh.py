@@ -235,6 +235,33 @@ def test_trace_through_gpu_built_stream(ctx, algo):
         assert V < 1.45 * Vs                      # the clustering trees stay near the SAH tree's traversal cost
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_geometry_that_already_lives_on_the_device(ctx, algo):
+    """A renderer's vertex and index buffers are device memory: the builders use them in place (no upload), check the indices
+    with a kernel, and produce the stream they produce from host arrays."""
+    sc = scenes.terrain(40)
+    v8 = np.zeros((sc.verts.shape[0], 8), np.float32)
+    v8[:, :3] = sc.verts
+    idx = np.ascontiguousarray(sc.faces.reshape(-1), np.uint32)
+    P = sc.triangle_count
+    want, _ = api.bvh_build_device(ctx, v8, 8, idx, P, algorithm=algo)
+    d_v, d_i = ctx.malloc(v8.nbytes), ctx.malloc(idx.nbytes)
+    try:
+        ctx.h2d(d_v, v8); ctx.h2d(d_i, idx)
+        got, _ = api.bvh_build_device(ctx, (d_v, v8.size), 8, d_i, P, algorithm=algo)
+        assert (got == want).all()
+        mixed, _ = api.bvh_build_device(ctx, (d_v, v8.size), 8, idx, P, algorithm=algo)          # device vertices, host indices
+        assert (mixed == want).all()
+        bad = idx.copy()
+        bad[7] = v8.shape[0]                                              # one index past the vertex buffer
+        ctx.h2d(d_i, bad)
+        with pytest.raises(api.RtsError) as e:
+            api.bvh_build_device(ctx, (d_v, v8.size), 8, d_i, P, algorithm=algo)
+        assert e.value.status == 1
+    finally:
+        ctx.free(d_v); ctx.free(d_i)
+
+
 def test_error_codes(ctx):
     v, idx = _soup(4, 1)
     with pytest.raises(api.RtsError) as e:
