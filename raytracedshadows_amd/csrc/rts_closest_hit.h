@@ -32,6 +32,38 @@ RTS_HD V3 primaryDirection(const Camera& c, uint32_t x, uint32_t y, uint32_t W, 
     return add(add(c.fwd, mul(c.right, sx)), mul(c.up, sy));
 }
 
+// One triangle against the best hit so far (a = {e0, tail index}, b = {e1, next}, t = {v0}): strictly nearer hits replace it,
+// so of two triangles at the same distance the one met first in depth-first order stays.
+RTS_HD void leafTest(const uint32_t* a, const uint32_t* b, const uint32_t* t, uint32_t node, V3 o, V3 d, Hit* best) {
+    V3 e0{ asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, e1{ asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
+    V3 v0{ asFloat(t[0]), asFloat(t[1]), asFloat(t[2]) };
+    V3 s1 = cross(d, e1);
+    float det = dot(s1, e0);
+    if (det != 0.0f) {
+        float invd = 1.0f / det;
+        V3 dd = sub(o, v0);
+        float b1 = dot(dd, s1) * invd;
+        V3 s2 = cross(dd, e0);
+        float b2 = dot(d, s2) * invd;
+        float tt = dot(e1, s2) * invd;
+        if (b1 >= 0.0f && b2 >= 0.0f && b1 + b2 <= 1.0f && tt > 0.0f && tt < best->t) { best->t = tt; best->leaf = node; }
+    }
+}
+
+// Slab test of an inner node (a = {bboxMin, -}, b = {bboxMax, next}) against [0, best t].
+RTS_HD bool boxTest(const uint32_t* a, const uint32_t* b, V3 o, V3 inv, float bestT) {
+    float lo[3] = { asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, hi[3] = { asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
+    float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
+    float t0 = 0.0f, t1 = bestT;
+    for (int k = 0; k < 3; ++k) {
+        float f = (hi[k] - oo[k]) * ii[k], n = (lo[k] - oo[k]) * ii[k];
+        float mx = f > n ? f : n, mn = f > n ? n : f;
+        if (mx < t1) t1 = mx;      // NaN (0*inf) compares false: the slab is ignored
+        if (mn > t0) t0 = mn;
+    }
+    return t1 >= t0;
+}
+
 RTS_HD Hit closestHit(const uint32_t* bvh, V3 o, V3 d) {
     const float inf = asFloat(0x7F800000u);
     const V3 inv{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
@@ -41,31 +73,10 @@ RTS_HD Hit closestHit(const uint32_t* bvh, V3 o, V3 d) {
         const uint32_t* a = bvh + (size_t)node * 8;
         const uint32_t* b = a + 4;
         if (a[3] != 0xFFFFFFFFu) {
-            const uint32_t* t = bvh + (size_t)a[3] * 4;
-            V3 e0{ asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, e1{ asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
-            V3 v0{ asFloat(t[0]), asFloat(t[1]), asFloat(t[2]) };
-            V3 s1 = cross(d, e1);
-            float det = dot(s1, e0);
-            if (det != 0.0f) {
-                float invd = 1.0f / det;
-                V3 dd = sub(o, v0);
-                float b1 = dot(dd, s1) * invd;
-                V3 s2 = cross(dd, e0);
-                float b2 = dot(d, s2) * invd;
-                float tt = dot(e1, s2) * invd;
-                if (b1 >= 0.0f && b2 >= 0.0f && b1 + b2 <= 1.0f && tt > 0.0f && tt < best.t) { best.t = tt; best.leaf = node; }
-            }
-        } else {
-            float lo[3] = { asFloat(a[0]), asFloat(a[1]), asFloat(a[2]) }, hi[3] = { asFloat(b[0]), asFloat(b[1]), asFloat(b[2]) };
-            float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
-            float t0 = 0.0f, t1 = best.t;
-            for (int k = 0; k < 3; ++k) {
-                float f = (hi[k] - oo[k]) * ii[k], n = (lo[k] - oo[k]) * ii[k];
-                float mx = f > n ? f : n, mn = f > n ? n : f;
-                if (mx < t1) t1 = mx;      // NaN (0*inf) compares false: the slab is ignored
-                if (mn > t0) t0 = mn;
-            }
-            if (t1 >= t0) { ++node; continue; }
+            leafTest(a, b, bvh + (size_t)a[3] * 4, node, o, d, &best);
+        } else if (boxTest(a, b, o, inv, best.t)) {
+            ++node;
+            continue;
         }
         node = b[3];
     }
@@ -74,10 +85,7 @@ RTS_HD Hit closestHit(const uint32_t* bvh, V3 o, V3 d) {
 
 // G-buffer texel: camera-relative position (Model.frag:39) and the face normal turned towards the viewer
 // (Model.frag:38 `gl_FrontFacing ? n : -n`; the harness has no vertex normals, so the geometric one is used).
-RTS_HD void shadePixel(const uint32_t* bvh, const Camera& c, uint32_t x, uint32_t y, uint32_t W, uint32_t H,
-                       float* position4, float* normal4) {
-    V3 d = primaryDirection(c, x, y, W, H);
-    Hit h = closestHit(bvh, c.eye, d);
+RTS_HD void writeTexel(const uint32_t* bvh, V3 d, Hit h, float* position4, float* normal4) {
     if (h.leaf == 0xFFFFFFFFu) {
         position4[0] = position4[1] = position4[2] = position4[3] = 0.0f;       // clear value (background)
         if (normal4) normal4[0] = normal4[1] = normal4[2] = normal4[3] = 0.0f;
@@ -94,6 +102,12 @@ RTS_HD void shadePixel(const uint32_t* bvh, const Camera& c, uint32_t x, uint32_
         if (dot(n, d) > 0.0f) s = -s;
         normal4[0] = n.x * s; normal4[1] = n.y * s; normal4[2] = n.z * s; normal4[3] = 0.0f;
     }
+}
+
+RTS_HD void shadePixel(const uint32_t* bvh, const Camera& c, uint32_t x, uint32_t y, uint32_t W, uint32_t H,
+                       float* position4, float* normal4) {
+    V3 d = primaryDirection(c, x, y, W, H);
+    writeTexel(bvh, d, closestHit(bvh, c.eye, d), position4, normal4);
 }
 
 // Combine.frag:18-37 with baseColor = 1 (the default white material, RayTracedShadows.cpp:1013-1018), one pixel:
