@@ -755,3 +755,180 @@ extern "C" void orc_order_experiment(const uint32_t* packed, const float* consta
     }
     out[0] = tiles; out[1] = sumU; out[2] = sumM; out[3] = sumV; out[4] = occl;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Analysis helper (not a checker of the product; it checks a THEOREM the product's wide kernels rest on, and
+// counts what such kernels would do).  A parent's box encloses its children's boxes (BVHBuilder.cpp:53-76: union by
+// min/max, exact), and the slab test of comp:61-73 is monotone in the box when no NaN arises (IEEE subtraction,
+// multiplication by a fixed 1/d and rounding are monotone): hit(child box) => hit(parent box).  So a ray reaches a leaf
+// iff it hits the box of the leaf's PARENT, and the boxes in between need not be tested.  orc_wide_packet_sim walks every
+// 8x8 tile as a packet over nodes that carry the boxes of their descendants `depth` levels down (depth 1: both children,
+// 2: four grandchildren, 3: eight), with a stack of (node, member mask), testing triangles for the rays that hit the box
+// of the leaf's parent; it compares the mask with anyHit() (out[7] = mismatching rays) and counts:
+// out[0] tiles, out[1] steps (wide nodes entered, one dependent fetch each), out[2] box tests (wave-wide groups of 16
+// VALU), out[3] member lanes summed over those tests, out[4] triangle tests (wave-wide), out[5] member lanes over them,
+// out[6] longest tile (steps), out[7] mismatches, out[8] box tests if a slot repeating the previous slot's box is
+// not tested again, out[9] sum over tiles of steps^2 (for the spread), out[10] rays whose 1/d is not finite-nonzero
+// (excluded: the product sends such waves to the exact lane-per-ray walk).
+// hist (nullable): 64 bins of steps per tile, bin = min(63, steps / histStep).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct WSlot { u32 boxNode; u32 ref; bool leaf; };     // boxNode = inner node whose box is tested (kInvalid: none)
+static void wideSlots(const u32* bvh, u32 n, u32 root, int d, std::vector<WSlot>& out, bool withRootBox = false) {
+    const u32 left = n + 1, right = bvh[(size_t)left * 8 + 7];
+    const u32 kids[2] = { left, right };
+    for (u32 c : kids) {
+        const bool leaf = bvh[(size_t)c * 8 + 3] != kInvalid;
+        if (leaf) out.push_back(WSlot{ (n == root && !withRootBox) ? kInvalid : n, c, true });
+        else if (d > 1) wideSlots(bvh, c, root, d - 1, out, withRootBox);
+        else out.push_back(WSlot{ c, c, false });
+    }
+}
+}
+
+extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constants, const void* light_v,
+                                    const float* positions, uint32_t W, uint32_t H, int depth, uint32_t histStep,
+                                    uint64_t* out, uint64_t* hist) {
+    const OLight& lt = *(const OLight*)light_v;
+    const u32* bvh = packed;
+    // depth >= 10: the slots are culled with the CHEAP conservative test of the product's wide kernels (one fma per
+    // plane against a per-ray constant that carries the slack, see wideRaySetup below) and a triangle hit only counts
+    // after the exact test of the leaf's parent box; out[11] = tests where the exact form hits and the cheap one does
+    // not (must be 0), out[12] = cheap hits that the exact form rejects (wasted work, not an error).
+    const bool cheap = depth >= 10;
+    if (cheap) depth -= 10;
+    uint64_t violations = 0, falsePos = 0;
+    float rootLo[3] = { u2f(bvh[0]), u2f(bvh[1]), u2f(bvh[2]) }, rootHi[3] = { u2f(bvh[4]), u2f(bvh[5]), u2f(bvh[6]) };
+    uint64_t tiles = 0, steps = 0, boxT = 0, boxLanes = 0, triT = 0, triLanes = 0, longest = 0, mism = 0, boxD = 0, sq = 0, unsafe = 0;
+    const uint32_t tx = W / 8, ty = H / 8;
+    std::vector<uint64_t> histAll(64, 0);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        std::vector<uint64_t> histLoc(64, 0);
+        std::vector<WSlot> slots;
+        std::vector<std::pair<u32, uint64_t>> stack;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4) reduction(+ : tiles, steps, boxT, boxLanes, triT, triLanes, mism, boxD, sq, unsafe, violations, falsePos) reduction(max : longest)
+#endif
+        for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
+            const uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
+            V3 o[64], d[64], inv[64]; float tm[64];
+            float cUp[64][3], cDn[64][3];
+            uint64_t live = 0, expect = 0;
+            for (u32 l = 0; l < 64; ++l) {
+                const size_t pix = (size_t)(by * 8 + l / 8) * W + bx * 8 + (l % 8);
+                V3 rel = { positions[pix * 4 + 0], positions[pix * 4 + 1], positions[pix * 4 + 2] };
+                genRay(constants, rel, lt, 0, &o[l], &tm[l], &d[l]);
+                inv[l] = V3{ 1.0f / d[l].x, 1.0f / d[l].y, 1.0f / d[l].z };
+                const bool safe = std::isfinite(o[l].x) && std::isfinite(o[l].y) && std::isfinite(o[l].z) &&
+                                  std::isfinite(inv[l].x) && std::isfinite(inv[l].y) && std::isfinite(inv[l].z) &&
+                                  inv[l].x != 0.f && inv[l].y != 0.f && inv[l].z != 0.f;
+                if (!safe) { ++unsafe; continue; }
+                if (cheap) {
+                    // wideRaySetup: plane*inv - c with c = o*inv -/+ slack;  slack >= 3.5u*E*|inv| + 2u*|o*inv| + tiny
+                    // covers both roundings of the exact form (fl(fl(P-o)*inv)) and the one of the fma, for every plane
+                    // P inside the root box (E = largest |P - o| there); see DESIGN.md 4.7 for the derivation
+                    const float oo[3] = { o[l].x, o[l].y, o[l].z }, ii[3] = { inv[l].x, inv[l].y, inv[l].z };
+                    bool ok = true;
+                    for (int a = 0; a < 3; ++a) {
+                        const float E = fmaxf(fabsf(rootLo[a] - oo[a]), fabsf(rootHi[a] - oo[a]));
+                        const float oi = oo[a] * ii[a];
+                        const float slack = (E * fabsf(ii[a])) * 4.76837158e-7f + fabsf(oi) * 2.38418579e-7f + 7.5e-37f;   // 8u, 4u, ~2^-120
+                        const float M = fmaxf(fabsf(rootLo[a]), fabsf(rootHi[a])) * fabsf(ii[a]);
+                        cUp[l][a] = oi - slack; cDn[l][a] = oi + slack;
+                        ok = ok && std::isfinite(slack) && M < 1e37f && fabsf(oi) < 1e37f && std::isfinite(cUp[l][a]) && std::isfinite(cDn[l][a]);
+                    }
+                    if (!ok) { ++unsafe; continue; }
+                }
+                live |= 1ull << l;
+                if (anyHit(bvh, o[l], tm[l], d[l], nullptr, nullptr)) expect |= 1ull << l;
+            }
+            uint64_t occluded = 0, mySteps = 0;
+            auto box = [&](u32 n, u32 l) {
+                const u32* a = bvh + (size_t)n * 8;
+                V3 pmin = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, pmax = { u2f(a[4]), u2f(a[5]), u2f(a[6]) };
+                return rayBox(o[l], inv[l], pmin, pmax);
+            };
+            auto boxCheap = [&](u32 n, u32 l) {
+                const u32* a = bvh + (size_t)n * 8;
+                const float lo[3] = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, hi[3] = { u2f(a[4]), u2f(a[5]), u2f(a[6]) };
+                const float ii[3] = { inv[l].x, inv[l].y, inv[l].z };
+                float t1 = INFINITY, t0 = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    const float farP = ii[k] > 0.f ? hi[k] : lo[k], nearP = ii[k] > 0.f ? lo[k] : hi[k];
+                    const float f = fmaf(farP, ii[k], -cUp[l][k]), nn = fmaf(nearP, ii[k], -cDn[l][k]);
+                    t1 = fminf(t1, f); t0 = fmaxf(t0, nn);
+                }
+                return t1 >= t0;
+            };
+            auto tri = [&](u32 n, u32 l) {
+                const u32* a = bvh + (size_t)n * 8; const u32* tt = bvh + (size_t)a[3] * 4;
+                V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(a[4]), u2f(a[5]), u2f(a[6]) }, v0 = { u2f(tt[0]), u2f(tt[1]), u2f(tt[2]) };
+                return rayTri(o[l], tm[l], d[l], v0, e0, e1);
+            };
+            stack.clear();
+            if (bvh[3] != kInvalid) {                     // a single triangle: the root is a leaf
+                for (u32 l = 0; l < 64; ++l) if (((live >> l) & 1) && tri(0, l)) occluded |= 1ull << l;
+                ++triT; triLanes += __builtin_popcountll(live);
+            } else {
+                uint64_t m = cheap ? live : 0;
+                if (!cheap) {
+                    for (u32 l = 0; l < 64; ++l) if (((live >> l) & 1) && box(0, l)) m |= 1ull << l;
+                    ++boxT; ++boxD; boxLanes += __builtin_popcountll(live);
+                }
+                if (m) stack.push_back({ 0u, m });
+            }
+            while (!stack.empty()) {
+                const u32 n = stack.back().first; uint64_t m = stack.back().second & ~occluded; stack.pop_back();
+                if (!m) continue;
+                ++mySteps;
+                slots.clear();
+                wideSlots(bvh, n, n, depth, slots, cheap);
+                const size_t base = stack.size();
+                u32 prevBox = kInvalid - 1;
+                uint64_t prevHit = 0;
+                for (const WSlot& s : slots) {
+                    uint64_t h = m & ~occluded;
+                    if (s.boxNode != kInvalid) {
+                        ++boxT; boxLanes += __builtin_popcountll(h);
+                        if (s.boxNode == prevBox) h &= prevHit;
+                        else {
+                            ++boxD;
+                            uint64_t hh = 0;
+                            for (u32 l = 0; l < 64; ++l) if ((h >> l) & 1) {
+                                if (!cheap) { if (box(s.boxNode, l)) hh |= 1ull << l; continue; }
+                                const bool c = boxCheap(s.boxNode, l), e = box(s.boxNode, l);
+                                if (e && !c) ++violations;
+                                if (c && !e) ++falsePos;
+                                if (c) hh |= 1ull << l;
+                            }
+                            prevBox = s.boxNode; prevHit = hh; h = hh;
+                        }
+                    }
+                    if (!h) continue;
+                    if (s.leaf) {
+                        ++triT; triLanes += __builtin_popcountll(h);
+                        for (u32 l = 0; l < 64; ++l) if (((h >> l) & 1) && tri(s.ref, l)) {
+                            // cheap mode: the hit counts only if the ray hits the box of the leaf's parent (exact form)
+                            const u32 parentBox = s.boxNode != kInvalid ? s.boxNode : n;
+                            if (!cheap || box(parentBox, l)) occluded |= 1ull << l;
+                        }
+                    } else stack.push_back({ s.ref, h });
+                }
+                std::reverse(stack.begin() + base, stack.end());   // first slot on top: DFS order
+            }
+            mism += __builtin_popcountll((occluded ^ expect) & live);
+            steps += mySteps; sq += mySteps * mySteps; if (mySteps > longest) longest = mySteps; ++tiles;
+            histLoc[std::min<uint64_t>(63, mySteps / (histStep ? histStep : 1))]++;
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        for (int i = 0; i < 64; ++i) histAll[i] += histLoc[i];
+    }
+    out[0] = tiles; out[1] = steps; out[2] = boxT; out[3] = boxLanes; out[4] = triT; out[5] = triLanes; out[6] = longest;
+    out[7] = mism; out[8] = boxD; out[9] = sq; out[10] = unsafe; out[11] = violations; out[12] = falsePos;
+    if (hist) for (int i = 0; i < 64; ++i) hist[i] = histAll[i];
+}
