@@ -612,6 +612,59 @@ int orc_max_threads(void) {
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// Combine pass, restated from /root/reference/Source/Shaders/Combine.frag:18-37 (checker for SURVEY.md 8 f4; written from
+// the shader, independently of the product's combinePixel):
+//     worldNormal = normal target, baseColor = 1 (the default white material, RayTracedShadows.cpp:1013-1018)
+//     directLight  = 1.25 * max(0.0, dot(worldNormal, lightDirection.xyz)) * shadowMask                  (frag:29)
+//     ambientLight = 0.15 + 0.05 * (1.0 - max(0.0f, dot(worldNormal, -cameraDirection.xyz)))             (frag:30)
+//     result.xyz   = baseColor * vec3(directLight + ambientLight)                                          (frag:32)
+//     discard where worldNormal == 0 (the target keeps its clear value, 0)                                (frag:35-36)
+// Every product is evaluated left to right as the shader spells it, in fp32 without contraction.  What the shader reads
+// from textures arrives here as arrays: shadowMask = mask byte / samples (R8_UNORM of a 0/1 mask in the reference; the
+// 16-sample extension stores the count of unoccluded samples).  Two stated extensions of the harness, shared with the
+// product's contract (include/rts_scene.h): cameraDirection is normalised first (the reference passes a unit vector,
+// the harness passes target - eye); for a point light lightDirection = normalize(light - worldPosition).
+// Output: UNORM8 of result.x, round to nearest (three equal channels).
+// ---------------------------------------------------------------------------------------------
+extern "C" void orc_combine(const float* constants, const void* light_v, const float* positions, const float* normals,
+                            const uint8_t* mask, uint32_t W, uint32_t H, uint8_t* rgb) {
+    const OLight* lt = (const OLight*)light_v;
+    const float* camPos = constants;                 // cameraPosition
+    const float* camDir = constants + 4;             // cameraDirection
+    const float* sunDir = constants + 8;             // lightDirection
+    float view[3];
+    {
+        const float len = sqrtf(camDir[0] * camDir[0] + camDir[1] * camDir[1] + camDir[2] * camDir[2]);
+        const float inv = len > 0.0f ? 1.0f / len : 1.0f;
+        for (int a = 0; a < 3; ++a) view[a] = len > 0.0f ? camDir[a] * inv : camDir[a];
+    }
+    const float samples = (lt && lt->nsamples > 1) ? (float)lt->nsamples : 1.0f;
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+        const float* N = normals + i * 4;
+        uint8_t out = 0;
+        if (!(N[0] == 0.0f && N[1] == 0.0f && N[2] == 0.0f)) {
+            float L[3];
+            if (lt && lt->type == 1) {
+                for (int a = 0; a < 3; ++a) L[a] = lt->xyz[a] - (camPos[a] + positions[i * 4 + a]);
+                const float len = sqrtf(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
+                if (len > 0.0f) { const float inv = 1.0f / len; for (int a = 0; a < 3; ++a) L[a] = L[a] * inv; }
+            } else {
+                for (int a = 0; a < 3; ++a) L[a] = lt ? lt->xyz[a] : sunDir[a];
+            }
+            const float shadowMask = (float)mask[i] / samples;
+            const float nDotL = N[0] * L[0] + N[1] * L[1] + N[2] * L[2];
+            const float nDotV = N[0] * (-view[0]) + N[1] * (-view[1]) + N[2] * (-view[2]);
+            const float directLight = 1.25f * (nDotL > 0.0f ? nDotL : 0.0f) * shadowMask;
+            const float ambientLight = 0.15f + 0.05f * (1.0f - (nDotV > 0.0f ? nDotV : 0.0f));
+            const float result = directLight + ambientLight;
+            const float scaled = result * 255.0f + 0.5f;
+            out = scaled >= 255.0f ? 255 : (scaled <= 0.0f ? 0 : (uint8_t)(int)scaled);
+        }
+        rgb[i * 3] = rgb[i * 3 + 1] = rgb[i * 3 + 2] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Analysis helper (not a checker): for every 8x8 pixel tile of a frame, how many DISTINCT nodes
 // do its 64 rays visit (what a wave-uniform sweep in increasing DFS index would iterate over),
 // against the longest single ray (what a lane-per-ray loop iterates over) and the sum.

@@ -36,11 +36,29 @@ struct rts_ctx {
     uint64_t launches = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
     void* d_scratch = nullptr; size_t scratchBytes = 0;    // working memory of the GPU builders, kept between builds
+    // GPU-private copy for the wide packet kernel (rts_wide.hip): derived from d_bvh on the device, never visible outside
+    void* d_wide = nullptr; size_t wideCap = 0;      // wide nodes (P * 128 B), triangle records (P * 64 B), parents (N * 4 B): one allocation
+    void* d_tris = nullptr;
+    void* d_parents = nullptr;
+    uint32_t* d_word = nullptr;              // 4 bytes for the validation kernel's verdict
+    uint32_t wideCount = 0, wideLevels = 0;
+    bool bvhEnclosed = false;                // pre-order binary tree whose boxes enclose their children's (validateKernel)
+    int wideCopy = 1;                        // option "wide_copy": build the private copy at upload
+    int wideLane = 1;                        // option "wide_lane": dissolved wide packets walk the wide nodes lane per ray
 };
 
 namespace {
 
 inline int hipStatus(hipError_t e) { return e == hipSuccess ? RTS_OK : RTS_ERR_HIP + (int)e; }
+}
+namespace rts {   // rts_wide.hip
+hipError_t validateStreamDevice(const void* d_packed, uint32_t P, uint32_t* d_word, uint32_t* flagsOut);
+size_t wideScratchBytes(uint32_t P);
+hipError_t buildWideDevice(const void* d_packed, uint32_t P, void* d_wide, void* d_tris, void* d_parents, void* d_scratch,
+                           uint32_t maxDepth, uint32_t* wideCount, uint32_t* levels);
+}
+extern "C" void* rts_ctx_scratch(rts_ctx* c, size_t bytes);
+namespace {
 #define RTS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipStatus(e_); } while (0)
 
 int ensure(void** p, size_t* have, size_t want) {
@@ -61,6 +79,41 @@ int fillParams(rts_ctx* ctx, TraceParams& p) {
     p.bvhOrdered = (ctx->bvhFinite && ctx->bvhOrdered) ? 1u : 0u;
     p.packetBudget = (uint32_t)ctx->packetBudget;
     p.packetShare = (uint32_t)ctx->packetShare;
+    p.wide = ctx->wideCount ? ctx->d_wide : nullptr;
+    p.tris = ctx->wideCount ? ctx->d_tris : nullptr;
+    p.primCount = ctx->P;
+    p.parents = ctx->wideCount ? (const uint32_t*)ctx->d_parents : nullptr;
+    p.wideBytes = (uint32_t)((size_t)ctx->P * 192u);
+    p.trisOffset = (uint32_t)((size_t)ctx->P * 128u);
+    p.wideLane = (uint32_t)ctx->wideLane;
+    return RTS_OK;
+}
+
+// The stream in c->d_bvh has just been installed (uploaded or adopted): what the kernels may assume about it is decided
+// on the device (one kernel over all nodes), then the private copy of the wide kernel is derived from it.  A stream that
+// breaks the layout rules is refused (RTS_ERR_BAD_BVH) and the context is left without a BVH.
+int finishInstall(rts_ctx* c, bool freeOnRefusal) {
+    uint32_t flags = 0xF;
+    hipError_t e = rts::validateStreamDevice(c->d_bvh, c->P, c->d_word, &flags);
+    if (e != hipSuccess || (flags & 1u)) {
+        if (freeOnRefusal) (void)hipFree(c->d_bvh);
+        c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; c->wideCount = 0;
+        return e != hipSuccess ? hipStatus(e) : RTS_ERR_BAD_BVH;
+    }
+    c->bvhFinite = !(flags & 2u);
+    c->bvhOrdered = !(flags & 4u);
+    c->bvhEnclosed = !(flags & 8u);
+    c->wideCount = 0; c->wideLevels = 0;
+    // (byte offsets inside the private copy are 32-bit: 192 bytes per triangle)
+    if (!c->wideCopy || !c->bvhFinite || !c->bvhOrdered || !c->bvhEnclosed || c->P < 2 || c->P > (1u << 24)) return RTS_OK;
+    int s = ensure(&c->d_wide, &c->wideCap, (size_t)c->P * 200 + 256);
+    c->d_tris = s == RTS_OK ? (char*)c->d_wide + (size_t)c->P * 128 : nullptr;
+    c->d_parents = s == RTS_OK ? (char*)c->d_wide + (size_t)c->P * 192 : nullptr;
+    void* scratch = s == RTS_OK ? rts_ctx_scratch(c, rts::wideScratchBytes(c->P)) : nullptr;
+    if (!scratch) return RTS_OK;                      // no memory for the copy: the stackless kernels need none
+    // (trees deeper than 512 levels -- chains of single-triangle splits -- keep the stackless kernels)
+    e = rts::buildWideDevice(c->d_bvh, c->P, c->d_wide, c->d_tris, c->d_parents, scratch, 512, &c->wideCount, &c->wideLevels);
+    if (e != hipSuccess) { c->wideCount = 0; return hipStatus(e); }
     return RTS_OK;
 }
 
@@ -140,6 +193,7 @@ int rts_ctx_create(int device, rts_ctx** out) {
     c->device = device;
     hipError_t e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_word, 256);
     if (e != hipSuccess) { delete c; return hipStatus(e); }
     *out = c;
     return RTS_OK;
@@ -154,6 +208,8 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_waveStats) (void)hipFree(c->d_waveStats);
     if (c->d_tileOrder) (void)hipFree(c->d_tileOrder);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_wide) (void)hipFree(c->d_wide);
+    if (c->d_word) (void)hipFree(c->d_word);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -166,17 +222,6 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     uint32_t P = 0;
     int s = rts_bvh_validate(packed, count, &P);
     if (s != RTS_OK) return s;
-    const uint64_t N = 2ull * P - 1;
-    bool finite = true, ordered = true;
-    for (uint64_t i = 0; i < 2 * N + P && finite; ++i) {
-        float f[3]; memcpy(f, &packed[i], 12);
-        finite = std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2]);
-    }
-    for (uint64_t i = 0; i < N && ordered; ++i) {
-        if (packed[2 * i].d != 0xFFFFFFFFu) continue;                 // leaves carry edges, not boxes
-        float lo[3], hi[3]; memcpy(lo, &packed[2 * i], 12); memcpy(hi, &packed[2 * i + 1], 12);
-        ordered = lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2];
-    }
     if (count * 16 >= 0xFFFFFF00ull) return RTS_ERR_BAD_BVH;           // 32-bit byte offsets on the device (top 256 B = "nothing")
     RTS_HIP(hipSetDevice(c->device));
     // the context only changes once the new copy is complete; a failure leaves it without a BVH, never with a torn one
@@ -185,8 +230,8 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     RTS_HIP(hipMalloc(&d, count * 16 + 64));          // + slack: the prefetching packet loop reads one node ahead
     hipError_t e = hipMemcpy(d, packed, count * 16, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return hipStatus(e); }
-    c->d_bvh = d; c->bvhVec4 = count; c->P = P; c->bvhFinite = finite; c->bvhOrdered = ordered;
-    return RTS_OK;
+    c->d_bvh = d; c->bvhVec4 = count; c->P = P;
+    return finishInstall(c, true);       // finite / ordered / enclosed are decided on the device; private wide copy
 }
 
 int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
@@ -199,6 +244,8 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "row_order")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->rowOrder = value; return RTS_OK; }
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
+    if (!strcmp(key, "wide_copy")) { c->wideCopy = value ? 1 : 0; return RTS_OK; }      // takes effect at the next upload / build
+    if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
@@ -223,6 +270,11 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "row_order")) { *value = c->rowOrder; return RTS_OK; }
     if (!strcmp(key, "bvh_finite")) { *value = c->bvhFinite ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "bvh_enclosed")) { *value = c->bvhEnclosed ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "wide_copy")) { *value = c->wideCopy; return RTS_OK; }
+    if (!strcmp(key, "wide_lane")) { *value = c->wideLane; return RTS_OK; }
+    if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
+    if (!strcmp(key, "wide_levels")) { *value = (int)c->wideLevels; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
 }
 
@@ -254,6 +306,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     const uint64_t pixels = (uint64_t)W * rows;
     if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_SHARE;
+    if ((variant == rts::V_WIDE || variant == rts::V_WIDE_C) && !p.wide) variant = rts::V_PACKET;     // no private copy for this stream (see finishInstall)
     uint32_t bw, bh;
     rts::tileShape(variant, c->blockWaves, &bw, &bh);
     if (n_stripes > 1 && band_rows % bh != 0) return RTS_ERR_INVALID_ARG;   // a band is a whole number of workgroup rows (8, 16 or 32 pixel rows)
@@ -450,15 +503,17 @@ void* rts_ctx_scratch(rts_ctx* c, size_t bytes) {
     return c->d_scratch;
 }
 
-// used by the GPU builder (rts_lbvh.hip): the context takes ownership of a packed stream that is already on the
-// device (finite vertices were checked there; LBVH boxes are min <= max by construction)
+// used by the GPU builder (rts_lbvh.hip): the context takes ownership of a packed stream that is already on the device
+// (RTS_OK), or refuses it and leaves it with the caller (any other status)
 int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t P) {
     if (!c || !d_packed || count != (size_t)5 * P - 2 || count * 16 >= 0xFFFFFF00ull) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_bvh) { void* old = c->d_bvh; c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; RTS_HIP(hipFree(old)); }
     c->d_bvh = d_packed;
-    c->bvhVec4 = count; c->P = P; c->bvhFinite = true; c->bvhOrdered = true;
-    return RTS_OK;
+    c->bvhVec4 = count; c->P = P;
+    // the same checks as for an uploaded stream, on the device: layout, finiteness (edges of finite vertices can
+    // overflow), box order, enclosure.  A refused stream stays the caller's to free.
+    return finishInstall(c, false);
 }
 
 // used by the harness (rts_primary.hip): the device copy of the packed stream, NULL before rts_ctx_set_bvh

@@ -129,7 +129,9 @@ RTS_HD uint8_t combinePixel(const CombineParams& c, const float* position4, cons
     }
     float ndl = dot(n, L); if (ndl < 0) ndl = 0;
     float ndv = dot(n, mul(c.viewDir, -1.0f)); if (ndv < 0) ndv = 0;
-    float v = 1.25f * ndl * ((float)mask / c.samples) + 0.15f + 0.05f * (1.0f - ndv);
+    const float direct = 1.25f * ndl * ((float)mask / c.samples);          // frag:29
+    const float ambient = 0.15f + 0.05f * (1.0f - ndv);                     // frag:30
+    float v = direct + ambient;                                             // frag:32 (baseColor = 1)
     int q = (int)(v * 255.0f + 0.5f); if (q > 255) q = 255; if (q < 0) q = 0;
     return (uint8_t)q;
 }

@@ -14,6 +14,9 @@ enum Variant {
     V_PACKET4 = 5,     // same, 4 rays per lane (16x16 px per wave)
     V_PACKET_PF = 6,   // V_PACKET with the sequential successor node prefetched into a second SGPR set
     V_SHARE = 7,       // lane-per-ray with work sharing inside the wave (idle lanes take half of a busy ray's range)
+    V_WIDE = 8,        // packet over the private WIDE nodes (rts_wide.hip): four grandchild boxes per dependent fetch,
+                       // cheap conservative slab test, triangle hits confirmed by the exact test of the leaf's parent box
+    V_WIDE_C = 9,      // V_WIDE with the loop compiled from C++ instead of hand-written (reference form of the same algorithm)
     V_COUNT,
     V_AUTO = -1        // packet for big launches, V_SHARE for small ones and for generic rays
 };
@@ -44,6 +47,13 @@ struct TraceParams {
     uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
+    const void* wide;         // private wide nodes (128 B each, root first) or NULL: V_WIDE falls back to V_PACKET
+    const void* tris;         // private triangle records (48 B each, leaves in stream order)
+    const uint32_t* parents;  // private: parent node of every node of the stream
+    uint32_t primCount;
+    uint32_t wideBytes;       // size of the private copy (wide nodes + triangle records, one allocation)
+    uint32_t trisOffset;      // byte offset of the triangle records in it (tris == wide + trisOffset)
+    uint32_t wideLane;        // dissolved wide packets continue lane per ray over the WIDE nodes (0: over the stream, stackless)
     float offsets[64][4];
 };
 

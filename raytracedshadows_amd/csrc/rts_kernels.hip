@@ -184,9 +184,13 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
     uint64_t tDissolve = 0;     // clock when the (last) packet of this wave dissolved
 };
 
-template <bool FAST>
+// CONFIRM (rays handed over by the wide packet walk, which culls with a conservative test): such a ray can stand inside a
+// subtree whose root box it does not hit by the exact test, and reach a leaf there through a miss link.  A triangle hit
+// then only counts if the ray hits the box of the leaf's PARENT by the exact test -- by the enclosure property that is
+// "the reference's walk reaches this leaf" (rts_wide.hip).  The parent's index comes from the private parent table.
+template <bool FAST, bool CONFIRM = false>
 __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
-                                              ShareDiag* diag = nullptr) {
+                                              ShareDiag* diag = nullptr, const uint32_t* parents = nullptr) {
     uint32_t node = live ? start : END, bound = END, owner = laneId();
     uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
@@ -262,7 +266,13 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
         const bool nextActive = next < bound;
         const uint32_t nv = nextActive ? next * 2u : OOB_VEC4;
         const u32x4 na = bvh.vec4(nv), nb = bvh.vec4(nv + 1u);
-        const bool hitNow = leaf && triHit(r, xyz(v0), xyz(a), xyz(b));
+        bool hitNow = leaf && triHit(r, xyz(v0), xyz(a), xyz(b));
+        if (CONFIRM && hitNow) {
+            const uint32_t parent = parents[node];
+            const u32x4 pa = bvh.vec4(parent * 2u), pb = bvh.vec4(parent * 2u + 1u);
+            hitNow = boxHit<FAST>(r, __uint_as_float(pa.x), __uint_as_float(pa.y), __uint_as_float(pa.z),
+                                  __uint_as_float(pb.x), __uint_as_float(pb.y), __uint_as_float(pb.z));
+        }
         uint64_t hits = __builtin_amdgcn_ballot_w64(hitNow);
         while (hits) {                                               // rare: record the owners that just got occluded
             const int l = __builtin_ctzll(hits);
@@ -532,6 +542,358 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// V_WIDE: the packet walks the private WIDE nodes (rts_wide.hip) with a stack of (node, member mask).
+//
+// One dependent fetch (128 B, two s_load_dwordx16) brings the boxes of the four nodes two levels down; every member ray
+// tests all four, the packet continues with the first slot somebody hit and pushes the others.  The stack lives in three
+// VGPRs, entry i in lane i (v_readlane / v_writelane with a scalar lane index); the masks on it are exact membership, so no
+// per-lane bookkeeping ("who waits where") is left.
+//
+// What is tested, and why the mask is still the reference's: by the enclosure property (see rts_wide.hip) the reference's
+// ray is occluded iff there is a leaf whose triangle it hits AND whose parent's box it hits (comp:61-73, exact
+// arithmetic).  Anything that only DECIDES WHICH leaves to look at may be any superset test.  So inner culling uses the
+// cheap form  t = fma(plane, 1/d, -(o/d -+ slack))  (10 VALU per box instead of 16: one fma per plane, the slack folded
+// into two per-ray constants) and only a triangle HIT is confirmed with the exact slab test of the slot's box (a leaf
+// slot carries its parent's box).  The slack covers the two roundings of the exact form and the one of the fma for every
+// plane inside the root box (derivation: DESIGN.md 4.7; checked exhaustively on the CPU by orc_wide_packet_sim: no exact
+// hit is ever missed).
+//
+// Dissolve: every `packetBudget` nodes the members per node are compared with the rays alive; below packetShare/16 (or
+// when the stack is nearly full) every unfinished ray continues the reference's stackless walk from the node of its
+// topmost stack entry, lane per ray with work sharing, confirming triangle hits (traverseShare<.., CONFIRM>).
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) u32x16* ConstWidePtr;
+typedef const __attribute__((address_space(4))) uint32_t* ConstU32Ptr;
+
+struct WideRay { F3 cU, cD; };                     // o/d - slack (for upper bounds), o/d + slack (for lower bounds)
+
+__device__ __forceinline__ uint64_t uniform64(const void* ptr) {
+    const uint64_t v = (uint64_t)(uintptr_t)ptr;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// slack >= 3.5u E |1/d| + 2u |o/d| + tiny, E = largest |plane - o| over the root box, u = 2^-24.  False when a product
+// could overflow (the wave then takes the exact lane-per-ray walk).
+__device__ __forceinline__ bool wideRaySetup(const Ray& r, const float* rootLo, const float* rootHi, WideRay& w) {
+    const float o[3] = { r.o.x, r.o.y, r.o.z }, inv[3] = { r.inv.x, r.inv.y, r.inv.z };
+    float cU[3], cD[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float E = __builtin_fmaxf(__builtin_fabsf(rootLo[a] - o[a]), __builtin_fabsf(rootHi[a] - o[a]));
+        const float oi = o[a] * inv[a];
+        const float slack = (E * __builtin_fabsf(inv[a])) * 4.76837158e-7f + __builtin_fabsf(oi) * 2.38418579e-7f + 7.5e-37f;
+        const float M = __builtin_fmaxf(__builtin_fabsf(rootLo[a]), __builtin_fabsf(rootHi[a])) * __builtin_fabsf(inv[a]);
+        cU[a] = oi - slack; cD[a] = oi + slack;
+        ok = ok && (slack < __builtin_inff()) && (M < 1e37f) && (__builtin_fabsf(oi) < 1e37f);
+    }
+    w.cU = F3{ cU[0], cU[1], cU[2] }; w.cD = F3{ cD[0], cD[1], cD[2] };
+    return ok;
+}
+
+// OCT 0..7: bit a set <=> 1/d component a is negative in every lane (far plane = bboxMin on that axis); 8: per lane.
+template <int OCT>
+__device__ __forceinline__ bool cheapBox(const float* lo, const float* hi, const F3& inv, const WideRay& w) {
+    float fx, fy, fz, nx, ny, nz;
+    if (OCT < 8) {
+        fx = __builtin_fmaf((OCT & 1) ? lo[0] : hi[0], inv.x, -w.cU.x); nx = __builtin_fmaf((OCT & 1) ? hi[0] : lo[0], inv.x, -w.cD.x);
+        fy = __builtin_fmaf((OCT & 2) ? lo[1] : hi[1], inv.y, -w.cU.y); ny = __builtin_fmaf((OCT & 2) ? hi[1] : lo[1], inv.y, -w.cD.y);
+        fz = __builtin_fmaf((OCT & 4) ? lo[2] : hi[2], inv.z, -w.cU.z); nz = __builtin_fmaf((OCT & 4) ? hi[2] : lo[2], inv.z, -w.cD.z);
+    } else {
+        const bool sx = inv.x < 0.f, sy = inv.y < 0.f, sz = inv.z < 0.f;
+        fx = __builtin_fmaf(sx ? lo[0] : hi[0], inv.x, -w.cU.x); nx = __builtin_fmaf(sx ? hi[0] : lo[0], inv.x, -w.cD.x);
+        fy = __builtin_fmaf(sy ? lo[1] : hi[1], inv.y, -w.cU.y); ny = __builtin_fmaf(sy ? hi[1] : lo[1], inv.y, -w.cD.y);
+        fz = __builtin_fmaf(sz ? lo[2] : hi[2], inv.z, -w.cU.z); nz = __builtin_fmaf(sz ? hi[2] : lo[2], inv.z, -w.cD.z);
+    }
+    const float t1 = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+    return t1 >= t0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Lane-per-ray walk over the WIDE nodes (what a dissolved wide packet continues in).
+//
+// The stackless lane-per-ray walk (traverseShare) pays one dependent fetch per node, and in a dissolved wave that fetch
+// usually misses the L2 (0.5 - 0.9 us per iteration measured: a wave waits for its slowest lane).  Here a lane fetches a
+// wide node (its own: 7 x 16 B) and decides four boxes per dependent fetch, so a ray needs about a third of the
+// iterations.  Every lane keeps its own stack of pending nodes in LDS (LANE_STACK entries, entry e of lane l at word
+// e * 64 + l: conflict-free); a push that does not fit is not lost: the node's index in the stream is remembered
+// (lowest one per lane) and those lanes finish with the stackless walk from there (any-hit is an OR over a superset of
+// tests; hits are confirmed against the leaf's parent box as everywhere in the wide kernels).
+// Slab test: the cheap form with the plane picked per lane by the sign of 1/d (16 VALU per box).
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t LANE_STACK = 16;
+
+__device__ __forceinline__ bool cheapBoxLane(const float* lo, const float* hi, const F3& inv, const WideRay& w) {
+    const bool sx = inv.x < 0.f, sy = inv.y < 0.f, sz = inv.z < 0.f;
+    const float fx = __builtin_fmaf(sx ? lo[0] : hi[0], inv.x, -w.cU.x), nx = __builtin_fmaf(sx ? hi[0] : lo[0], inv.x, -w.cD.x);
+    const float fy = __builtin_fmaf(sy ? lo[1] : hi[1], inv.y, -w.cU.y), ny = __builtin_fmaf(sy ? hi[1] : lo[1], inv.y, -w.cD.y);
+    const float fz = __builtin_fmaf(sz ? lo[2] : hi[2], inv.z, -w.cU.z), nz = __builtin_fmaf(sz ? hi[2] : lo[2], inv.z, -w.cD.z);
+    const float t1 = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+    return t1 >= t0;
+}
+
+struct LaneWalk {
+    __amdgpu_buffer_rsrc_t priv;   // the private copy: wide nodes, then the triangle records (one allocation)
+    uint32_t trisOff;              // byte offset of the triangle records in it
+    uint32_t* stack;               // this wave's LANE_STACK * 64 words of LDS
+    uint32_t sp = 0;               // entries on this lane's stack
+    uint32_t lostNode = END, lostLeaf = END;   // lowest refs among the items that did not fit on it (refs grow with the stream index)
+
+    // byte offset (in the private copy) of what an item refers to: a wide node, or (bit 0 set) a triangle record
+    __device__ __forceinline__ uint32_t offsetOf(uint32_t ref) const { return (ref & 1u) ? trisOff + (ref - 1u) : ref; }
+    __device__ __forceinline__ void push(uint32_t ref, bool doIt) {
+        const bool fits = doIt && sp < LANE_STACK;
+        if (fits) { stack[sp * 64u + laneId()] = ref; ++sp; }
+        if (doIt && !fits) {                                    // remember where the stackless walk has to start (no fetch here:
+            if (ref & 1u) lostLeaf = ref < lostLeaf ? ref : lostLeaf;   //  wide nodes and triangle records are numbered in stream order)
+            else lostNode = ref < lostNode ? ref : lostNode;
+        }
+    }
+    // stream index of the lowest item that was lost (END: none): dword 28 of a wide node, dword 9 of a triangle record
+    __device__ __forceinline__ uint32_t lostIndex() const {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(priv, (int)(lostNode != END ? lostNode + 112u : 0xFFFFFF00u), 0, 0);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(priv, (int)(lostLeaf != END ? offsetOf(lostLeaf) + 36u : 0xFFFFFF00u), 0, 0);
+        const uint32_t ia = lostNode != END ? a : END, ib = lostLeaf != END ? b : END;
+        return ia < ib ? ia : ib;
+    }
+    __device__ __forceinline__ uint32_t pop(bool doIt) {
+        uint32_t v = END;
+        if (doIt && sp > 0) { --sp; v = stack[sp * 64u + laneId()]; }
+        return v;
+    }
+};
+
+// `cur`: the item this lane takes up first (a wide node, or a triangle record with bit 0 set), END = nothing; pending
+// items are on the lane's stack.  One iteration = one item per lane = ONE memory latency: seven 16-byte loads from the
+// item's offset (a node uses all of them, a triangle record the first three), then either four box tests (every slot
+// somebody hit becomes an item: the first is taken up next, the others are pushed) or one triangle test.
+__device__ __forceinline__ bool laneWideWalk(LaneWalk& lw, const Ray& r, const WideRay& w, uint32_t cur, ShareDiag* diag) {
+    bool occluded = false;
+    for (;;) {
+        const bool active = cur != END;
+        const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+        if (act == 0) break;
+        if (diag && diag->on) { diag->iterations += 1u; diag->laneSteps += (uint32_t)__builtin_popcountll(act); }
+        const bool isLeaf = active && (cur & 1u);
+        const bool isNode = active && !(cur & 1u);
+        const uint32_t off = active ? lw.offsetOf(cur) : 0xFFFFFF00u;      // beyond the buffer: zeros, no memory access
+        u32x4 q[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[i] = __builtin_amdgcn_raw_buffer_load_b128(lw.priv, (int)(off + 16u * i), 0, 0);
+        // ---- a triangle (comp:41-59), then -- only on a hit -- the exact slab test of its leaf's parent box (comp:61-73)
+        if (__builtin_amdgcn_ballot_w64(isLeaf) != 0) {
+            const F3 v0{ __uint_as_float(q[0].x), __uint_as_float(q[0].y), __uint_as_float(q[0].z) };
+            const F3 e0{ __uint_as_float(q[0].w), __uint_as_float(q[1].x), __uint_as_float(q[1].y) };
+            const F3 e1{ __uint_as_float(q[1].z), __uint_as_float(q[1].w), __uint_as_float(q[2].x) };
+            bool t = isLeaf && triHit(r, v0, e0, e1);
+            if (__builtin_amdgcn_ballot_w64(t) != 0)                    // the parent's box travels in the record (dwords 10-15)
+                t = t && boxHit<true>(r, __uint_as_float(q[2].z), __uint_as_float(q[2].w), __uint_as_float(q[3].x),
+                                      __uint_as_float(q[3].y), __uint_as_float(q[3].z), __uint_as_float(q[3].w));
+            occluded = occluded || t;
+        }
+        // ---- a wide node: four cheap box tests; every slot hit is an item
+        uint32_t next = END;
+        if (__builtin_amdgcn_ballot_w64(isNode) != 0) {
+            float pl[24];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                pl[4 * i + 0] = __uint_as_float(q[i].x); pl[4 * i + 1] = __uint_as_float(q[i].y);
+                pl[4 * i + 2] = __uint_as_float(q[i].z); pl[4 * i + 3] = __uint_as_float(q[i].w);
+            }
+            const uint32_t ref[4] = { q[6].x, q[6].y, q[6].z, q[6].w };
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {                           // last slot first: the first one ends up as `next`
+                const bool hit = isNode && ref[k] != END && cheapBoxLane(&pl[6 * k], &pl[6 * k + 3], r.inv, w);
+                lw.push(next, hit && next != END);
+                next = hit ? ref[k] : next;
+            }
+        }
+        if (occluded) lw.sp = 0;                                     // nothing left to prove for this ray
+        const uint32_t popped = lw.pop(active && !occluded && next == END);
+        cur = (!active || occluded) ? END : (next != END ? next : popped);
+    }
+    return occluded;
+}
+
+// A dissolved wide packet: every pending (node, members) is on the stack.  A ray continues the reference's stackless walk
+// (lane per ray, work sharing, triangle hits confirmed) from the LOWEST node index among the entries it is a member of:
+// everything it still has to look at lies at or after that node in the stream.
+__device__ __forceinline__ bool wideDissolve(const TraceParams& p, const NodeStream& bvh, const Ray& r, const WideRay& w, uint64_t occ,
+                                             uint32_t sp, uint32_t stRef, uint32_t stLo, uint32_t stHi, uint32_t* lds,
+                                             uint32_t* laneStack, ShareDiag* diag) {
+    const uint64_t wideAddr = uniform64(p.wide);
+    if (diag && diag->on) diag->tDissolve = __builtin_amdgcn_s_memtime();
+    auto entryMask = [&](uint32_t e) {
+        return ((((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)stHi, (int)e)) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)stLo, (int)e)) & ~occ;
+    };
+    if (p.wideLane && laneStack) {
+        // every ray takes its pending nodes onto a stack of its own and walks the wide nodes alone
+        LaneWalk lw;
+        lw.priv = __builtin_amdgcn_make_buffer_rsrc((void*)p.wide, 0, (int)p.wideBytes, 0x00020000);
+        lw.trisOff = p.trisOffset;
+        lw.stack = laneStack;
+        for (uint32_t e = 0; e < sp; ++e) {
+            const uint64_t m = entryMask(e);
+            if (m == 0) continue;
+            const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)stRef, (int)e);
+            lw.push(eref, __builtin_amdgcn_inverse_ballot_w64(m));
+        }
+        const uint32_t first = lw.pop(true);
+        bool h = laneWideWalk(lw, r, w, first, diag);
+        // rays whose stack overflowed finish with the stackless walk from the lowest node they could not keep
+        if (__builtin_amdgcn_ballot_w64((lw.lostNode != END || lw.lostLeaf != END) && !h) != 0) {
+            const uint32_t from = h ? END : lw.lostIndex();
+            h = traverseShare<true, true>(bvh, r, from != END, from, lds, diag, p.parents) || h;
+        }
+        return __builtin_amdgcn_inverse_ballot_w64(occ) || h;
+    }
+    uint32_t start = END;
+    for (uint32_t e = 0; e < sp; ++e) {
+        const uint64_t m = entryMask(e);
+        if (m == 0) continue;
+        const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)stRef, (int)e);
+        const uint32_t self = *(ConstU32Ptr)(uintptr_t)(wideAddr + eref + 112u);
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) start = self < start ? self : start;
+    }
+    const bool h = traverseShare<true, true>(bvh, r, start != END, start, lds, diag, p.parents);
+    return __builtin_amdgcn_inverse_ballot_w64(occ) || h;
+}
+
+#include "rts_wide_asm.inc"
+
+static constexpr uint32_t WIDE_STACK_LIMIT = 60;   // entries on the stack when a node is taken up (it pushes at most 3)
+
+template <int OCT>
+__device__ __forceinline__ bool wideWalk(const TraceParams& p, const NodeStream& bvh, const Ray& r, const WideRay& w,
+                                         uint64_t liveMask, uint32_t* lds, uint32_t* laneStack, int32_t* dissolved, ShareDiag* diag) {
+    const uint64_t wideAddr = uniform64(p.wide), triAddr = uniform64(p.tris);
+    uint32_t stRef = 0, stLo = 0, stHi = 0;            // the stack: entry i lives in lane i
+    uint32_t sp = 0;
+    uint64_t occ = 0;
+    uint32_t curRef = 0;
+    uint64_t curM = liveMask;
+    bool have = true, dissolve = false;
+    const uint32_t window = p.packetBudget, thr = p.packetBudget * p.packetShare;
+    uint32_t acc = 0, left = window;
+    auto push = [&](uint32_t ref, uint64_t m) {
+        // (lane select through M0: a VOP3 instruction may read one SGPR, and the data is one already)
+        asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                     : "+v"(stRef), "+v"(stLo), "+v"(stHi)
+                     : "s"(ref), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(sp)
+                     : "m0");
+        ++sp;
+    };
+    auto entryMask = [&](uint32_t e) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)stHi, (int)e) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)stLo, (int)e);
+    };
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            curRef = (uint32_t)__builtin_amdgcn_readlane((int)stRef, (int)sp);
+            curM = entryMask(sp) & ~occ;
+            if (curM == 0) continue;
+        }
+        have = false;
+        acc += (uint32_t)__builtin_popcountll(curM);
+        if (--left == 0) {
+            const uint32_t alive = (uint32_t)__builtin_popcountll(liveMask & ~occ);
+            dissolve = acc * 16u < alive * thr;
+            acc = 0; left = window;
+        }
+        if (dissolve || sp > WIDE_STACK_LIMIT) { push(curRef, curM); dissolve = true; break; }
+        const ConstWidePtr np = (ConstWidePtr)(uintptr_t)(wideAddr + curRef);
+        const u32x16 n0 = np[0], n1 = np[1];
+        float pl[24];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) pl[d] = __uint_as_float(n0[d]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) pl[16 + d] = __uint_as_float(n1[d]);
+        const uint32_t ref[4] = { n1[8], n1[9], n1[10], n1[11] };
+        uint64_t h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = __builtin_amdgcn_ballot_w64(cheapBox<OCT>(&pl[6 * k], &pl[6 * k + 3], r.inv, w)) & curM;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                   // leaf slots somebody hit: one triangle each
+            if (h[k] == 0 || !(ref[k] & 1u) || ref[k] == END) continue;
+            const ConstVec4Ptr tp = (ConstVec4Ptr)(uintptr_t)(triAddr + (ref[k] - 1u));     // 64-byte record
+            const u32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const F3 v0{ __uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z) };
+            const F3 e0{ __uint_as_float(t0.w), __uint_as_float(t1.x), __uint_as_float(t1.y) };
+            const F3 e1{ __uint_as_float(t1.z), __uint_as_float(t1.w), __uint_as_float(t2.x) };
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(h[k] & ~occ);
+            bool t = mine && triHit(r, v0, e0, e1);
+            if (__builtin_amdgcn_ballot_w64(t) != 0) {
+                // the hit counts iff the reference's walk reaches this leaf: exact slab test of its parent's box
+                t = t && boxHit<true>(r, pl[6 * k], pl[6 * k + 1], pl[6 * k + 2], pl[6 * k + 3], pl[6 * k + 4], pl[6 * k + 5]);
+                occ |= __builtin_amdgcn_ballot_w64(t);
+            }
+        }
+        uint32_t candRef = 0;
+        uint64_t candM = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {                                  // inner slots, last first: the first ends up as `cur`
+            const uint64_t m = h[k] & ~occ;
+            if (m == 0 || (ref[k] & 1u)) continue;
+            if (candM != 0) push(candRef, candM);
+            candRef = ref[k]; candM = m;
+        }
+        if (candM != 0) { curRef = candRef; curM = candM; have = true; }
+    }
+    if (dissolved) *dissolved = dissolve ? -1 : 0;
+    if (!dissolve) return __builtin_amdgcn_inverse_ballot_w64(occ);
+    return wideDissolve(p, bvh, r, w, occ, sp, stRef, stLo, stHi, lds, laneStack, diag);
+}
+
+template <bool ASM>
+__device__ __forceinline__ bool traverseWide(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t* lds,
+                                             uint32_t* laneStack, int32_t* dissolved, ShareDiag* diag) {
+    const uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);
+    if (dissolved) *dissolved = 0;
+    if (liveMask == 0) return false;
+    const u32x8 root = *(ConstNodePtr)(uintptr_t)uniform64(p.bvh);          // node 0: the root's box
+    const float rootLo[3] = { __uint_as_float(root.s0), __uint_as_float(root.s1), __uint_as_float(root.s2) };
+    const float rootHi[3] = { __uint_as_float(root.s4), __uint_as_float(root.s5), __uint_as_float(root.s6) };
+    WideRay w;
+    const bool ok = wideRaySetup(r, rootLo, rootHi, w) && raySafe(r);
+    if (__builtin_amdgcn_ballot_w64(live && !ok) != 0)                       // a NaN or an overflow could occur: exact walk
+        return traverseShare<false>(bvh, r, live, 0u, lds);
+    const uint32_t oct = (__float_as_uint(r.inv.x) >> 31) | ((__float_as_uint(r.inv.y) >> 31) << 1) | ((__float_as_uint(r.inv.z) >> 31) << 2);
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)oct, __builtin_ctzll(liveMask));
+    const uint32_t form = (uint32_t)__builtin_amdgcn_readfirstlane((__builtin_amdgcn_ballot_w64(live && oct != first) == 0) ? (int)first : 8);
+    if constexpr (ASM) {
+        // the loop in gfx950 assembly (rts_wide_asm.inc, tools/gen_wide_asm.py); the C++ form below is the same algorithm
+        uint32_t stRef = 0, stLo = 0, stHi = 0, sp = 0;
+        uint64_t occ = 0;
+        const uint64_t liveU = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(liveMask >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)liveMask);
+        const uint32_t st = wideDescend(form, (const void*)(uintptr_t)uniform64(p.wide), (const void*)(uintptr_t)uniform64(p.tris), r, w,
+                                        liveU, occ, sp, stRef, stLo, stHi, p.packetBudget, p.packetBudget * p.packetShare);
+        if (dissolved) *dissolved = st ? -1 : 0;
+        if (st == 0) return __builtin_amdgcn_inverse_ballot_w64(occ);
+        return wideDissolve(p, bvh, r, w, occ, sp, stRef, stLo, stHi, lds, laneStack, diag);
+    } else {
+        switch (form) {
+        case 0: return wideWalk<0>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 1: return wideWalk<1>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 2: return wideWalk<2>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 3: return wideWalk<3>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 4: return wideWalk<4>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 5: return wideWalk<5>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 6: return wideWalk<6>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        case 7: return wideWalk<7>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        default: return wideWalk<8>(p, bvh, r, w, liveMask, lds, laneStack, dissolved, diag);
+        }
+    }
+}
+
 template <int VARIANT, bool FAST>
 __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t* lds) {
     if (VARIANT == V_SHARE) return traverseShare<FAST>(bvh, r, live, 0u, lds);
@@ -644,11 +1006,14 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // SOFT = more than one sample per pixel: only then the G-buffer position has to stay in registers across the walk.
 // PLAIN = the everyday launch (natural tile order on a 2-D grid, one contiguous row range, no diagnostics): the scalar
 // prologue that sorts out the other cases is compiled away.
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false>
+// WIDE = the walk over the private wide nodes (K = 1, WPB = 1): 1 = the loop in assembly, 2 = the same loop compiled.
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
+    __shared__ uint32_t laneStacks[WIDE != 0 ? WPB : 1][WIDE != 0 ? LANE_STACK * 64 : 1];   // per-lane stacks of the wide lane walk (4 KB per wave)
+    uint32_t* laneStack = WIDE != 0 ? laneStacks[threadIdx.x >> 6] : nullptr;
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx = blockIdx.x, by = dispatchRow(p, blockIdx.y);       // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
@@ -690,7 +1055,8 @@ void shadowMaskPacketKernel(TraceParams p) {
             asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
             tReady = __builtin_amdgcn_s_memtime();
         }
-        traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
+        if constexpr (WIDE != 0) occluded[0] = traverseWide<WIDE == 1>(p, bvh, r[0], live[0], lds, laneStack, &left, &shareDiag);
+        else traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -763,12 +1129,16 @@ const char* kernelName(int variant, bool mask) {
     case V_PACKET4: return mask ? "shadowMaskPacketKernel<4>" : "traceRaysKernel<3>";
     case V_PACKET_PF: return mask ? "shadowMaskPacketKernel<1,pf>" : "traceRaysKernel<3>";
     case V_SHARE: return mask ? "shadowMaskKernel<7>" : "traceRaysKernel<7>";
+    case V_WIDE: return mask ? "shadowMaskPacketKernel<1,wide>" : "traceRaysKernel<7>";
+    case V_WIDE_C: return mask ? "shadowMaskPacketKernel<1,wide,compiled>" : "traceRaysKernel<7>";
     }
     return "?";
 }
 
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH) {
     const bool packet = variant >= V_PACKET && variant <= V_PACKET_PF;
+    if (variant == V_WIDE_C) { *blockW = 8u; *blockH = 8u; return; }           // always one wave tile per workgroup
+    if (variant == V_WIDE) { *blockW = *blockH = wavesPerBlock == 4 ? 16u : 8u; return; }
     const uint32_t f = (packet && wavesPerBlock == 1) ? 1u : 2u;                // block = f x f wave tiles
     *blockW = f * ((variant == V_PACKET2 || variant == V_PACKET4) ? 16u : 8u);
     *blockH = f * (variant == V_PACKET4 ? 16u : 8u);
@@ -778,6 +1148,25 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     dim3 grid(p.gridBlocks), block(256);
     if (p.grid2d) grid = dim3(p.blocksX, p.blocksY);
     const bool soft = p.nsamples > 1;
+    if (variant == V_WIDE && wavesPerBlock == 4) {                       // 2 x 2 tiles per workgroup: neighbours share the scalar cache
+        if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, true, false, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, false, false, 1>), grid, block, 0, stream, p);
+        return hipGetLastError();
+    }
+    if (variant == V_WIDE) {
+        dim3 b1(64);
+        if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
+        else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1>), grid, b1, ldsPad, stream, p);
+        else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 1>), grid, b1, ldsPad, stream, p);
+        return hipGetLastError();
+    }
+    if (variant == V_WIDE_C) {
+        dim3 b1(64);
+        if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 2>), grid, b1, ldsPad, stream, p);
+        else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 2>), grid, b1, ldsPad, stream, p);
+        return hipGetLastError();
+    }
     if (variant >= V_PACKET && variant <= V_PACKET_PF && wavesPerBlock == 1) {
         dim3 b1(64);
         switch (variant) {
@@ -814,7 +1203,7 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
     case V_STRAIGHT: hipLaunchKernelGGL(traceRaysKernel<V_STRAIGHT>, grid, block, 0, stream, p); break;
     case V_WHILEWHILE: hipLaunchKernelGGL(traceRaysKernel<V_WHILEWHILE>, grid, block, 0, stream, p); break;
     case V_POSTPONE: hipLaunchKernelGGL(traceRaysKernel<V_POSTPONE>, grid, block, 0, stream, p); break;
-    case V_SHARE: hipLaunchKernelGGL(traceRaysKernel<V_SHARE>, grid, block, 0, stream, p); break;
+    case V_SHARE: case V_WIDE: case V_WIDE_C: hipLaunchKernelGGL(traceRaysKernel<V_SHARE>, grid, block, 0, stream, p); break;
     case V_PACKET: case V_PACKET2: case V_PACKET4: case V_PACKET_PF:
         hipLaunchKernelGGL(traceRaysKernel<V_PACKET>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;

@@ -53,6 +53,8 @@ def main():
             d_mask = ctx.malloc(W * H)
             ctx.h2d(d_pos, wl.positions)
             nvar = ctx.get_option("kernel_count")
+            print(f"[{cfg}] wide copy: {ctx.get_option('wide_nodes')} nodes in {ctx.get_option('wide_levels')} levels, "
+                  f"enclosed {ctx.get_option('bvh_enclosed')}", flush=True)
             variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
             combos = [{}]
             for k, vs in sweeps:

@@ -178,6 +178,23 @@ def epsilon_for(f, diff=13):
     return np.float32(_o.orc_epsilon_for(np.float32(f), diff))
 
 
+_o.orc_combine.restype = None
+_o.orc_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+
+
+def combine(constants_array, light, positions, normals, mask):
+    """Combine.frag:18-37 restated (orc_combine): uint8[H, W, 3].  light: an OLight, or None for the reference's
+    directional light taken from the constants."""
+    H, W = mask.shape
+    k = np.ascontiguousarray(constants_array, np.float32)
+    positions = np.ascontiguousarray(positions, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    _o.orc_combine(_p(k), C.byref(light) if light is not None else None, _p(positions), _p(normals), _p(mask), W, H, _p(rgb))
+    return rgb
+
+
 def order_experiment(packed, constants_array, light, positions, W, H, mode):
     """Visit statistics under another child order (experiment, see orc_order_experiment): dict of per-ray / per-tile means."""
     packed = np.ascontiguousarray(packed, np.uint32)

@@ -603,7 +603,7 @@ def test_gbuffer_pass_on_the_gpu_is_bit_identical_to_the_oracle(ctx, scene, W, H
 
 def test_whole_frame_on_the_device_gbuffer_mask_combine_and_blob(ctx, tmp_path):
     """SURVEY.md 8 f4 on the GPU: G-buffer -> shadow mask -> combine pass (Combine.frag:18-37) without leaving the device,
-    against the host combine of the oracle's mask; the packed stream goes through the blob file (save/load) first.
+    against the oracle's combine (orc_combine) of the oracle's mask; the packed stream goes through the blob file first.
     Point light, 16-sample soft shadows and the reference's directional light."""
     wl = workloads.prepare("atrium", 640, 360)
     W, H, sc = wl.W, wl.H, wl.scene
@@ -621,9 +621,10 @@ def test_whole_frame_on_the_device_gbuffer_mask_combine_and_blob(ctx, tmp_path):
             ctx.synchronize()
             got = np.zeros((H, W, 3), np.uint8)
             ctx.d2h(got, d_rgb)
-            mask, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(light, wl.constants),
-                                            pos, W, H)
-            want = api.combine(wl.constants, light, pos, nrm, mask)
+            olight = oracle.light_from_product(light, wl.constants)
+            mask, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, pos, W, H)
+            # the checker is the ORACLE's restatement of Combine.frag:18-37 (orc_combine), not the product's own host build
+            want = oracle.combine(wl.constants.as_array(), olight if light is not None else None, pos, nrm, mask)
             assert (got == want).all(), f"{(got != want).any(axis=2).sum()} pixels differ"
             assert want.max() > 100 and (want[nrm[..., :3].any(axis=2)] >= int(0.15 * 255)).all()
         with pytest.raises(api.RtsError):

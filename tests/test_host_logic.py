@@ -96,6 +96,24 @@ def test_gbuffer_normals_and_combine(tmp_path):
     assert head.startswith(b"P6\n96 64\n255\n")
 
 
+def test_host_combine_pass_equals_the_oracles_restatement_of_combine_frag():
+    """the product's combine pass (host build of the per-pixel code the GPU pass shares) against
+    orc_combine, the oracle's own restatement of Combine.frag:18-37 -- point light, 16-sample soft shadows (mask =
+    count of unoccluded samples), the reference's directional light from the constants block, and a directional rts_light."""
+    wl = workloads.prepare("atrium", 160, 90, via_obj=False)
+    W, H, sc = wl.W, wl.H, wl.scene
+    pos, nrm, _ = oracle.primary_gbuffer(wl.packed, sc.eye, sc.target, sc.fovy, W, H)
+    lights = [wl.light, workloads.relight(wl, "point", 16).light, None,
+              api.Light.make(api.Light.DIRECTIONAL, [0.3, 0.8, 0.5])]
+    for light in lights:
+        olight = oracle.light_from_product(light, wl.constants)
+        mask, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, pos, W, H)
+        got = api.combine(wl.constants, light, pos, nrm, mask)
+        want = oracle.combine(wl.constants.as_array(), olight if light is not None else None, pos, nrm, mask)
+        assert (got == want).all(), f"{(got != want).any(axis=2).sum()} pixels differ"
+        assert want.max() > 100 and len(np.unique(want)) > 8
+
+
 def test_bvh_blob_round_trip(tmp_path):
     wl = workloads.prepare("cornell", 8, 8, via_obj=False)
     path = api.save_bvh(str(tmp_path / "c.bvh"), wl.packed)

@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="city_4k")
     ap.add_argument("--block-waves", default="1")
+    ap.add_argument("--kernel", type=int, default=3)
     args = ap.parse_args()
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config, cache=True)
@@ -28,7 +29,7 @@ def main():
     with api.ShadowContext(0) as ctx:
         d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
         ctx.h2d(d_pos, wl.positions)
-        ctx.set_option("kernel", 3)
+        ctx.set_option("kernel", args.kernel)
 
         def go():
             ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
@@ -78,6 +79,11 @@ def main():
                 mid = (edges[:-1] + edges[1:]) / 2
                 infl = [int(((t0 <= m) & (t1 > m)).sum()) for m in mid]
                 print("    in flight per 5% slice: " + " ".join(str(v) for v in infl))
+                xi = xcc.astype(np.int64)
+                per_xcc = [float(((r1 - r0)[xi == x]).sum() / 100.0 / span_us) for x in range(8)]
+                print("    mean waves in flight per XCC (1024 slots each): " + " ".join(f"{v:.0f}" for v in per_xcc))
+                mid_t = 0.5 * span_us
+                print("    waves in flight per XCC at mid-frame: " + " ".join(str(int(((t0 <= mid_t) & (t1 > mid_t) & (xi == x)).sum())) for x in range(8)))
                 late = t1 > 0.85 * span_us
                 ty = ((st[ok, 3] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
                 rows = ty[late]

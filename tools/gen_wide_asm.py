@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Generates raytracedshadows_amd/csrc/rts_wide_asm.inc: the hand-written gfx950 loop of the WIDE packet kernel
+(rts_kernels.hip, 'V_WIDE'; data layout: rts_wide.hip), instantiated for the 8 sign octants of the ordered slab test and
+the generic form.  The .inc file is committed; re-run after editing:
+
+    python tools/gen_wide_asm.py
+
+One iteration = one wide node: two s_load_dwordx16 (128 B), four CHEAP slab tests (10 VALU each, EXEC = the members, so
+the compare results are membership masks as they come), then per slot that somebody hit: a leaf slot runs the triangle
+test for the lanes that hit its box and confirms triangle hits with the EXACT slab test of that box (comp:61-73); the
+first inner slot becomes the next node, further ones are pushed (node, mask) on the stack that lives in three VGPRs
+(entry i in lane i; v_writelane / v_readlane through M0).
+
+Fixed scratch SGPRs (declared as clobbers), relative to SGPR_BASE = 20:
+    N[0:31]   +0..+31   the wide node: slot k = N[6k..6k+2] bboxMin, N[6k+3..6k+5] bboxMax; N[24+k] ref; N[28] own node index
+    T[0:15]   +32..+47  triangle record: v0.xyz, e0.xyz, e1.xyz, leaf node, parent's bboxMin, bboxMax (unused here: the slot has it)
+    H0..H3    +48..+55  members that hit slot k          M   +56,57  members of the current node
+    NXM       +58,59    members of the next node        NXREF +60   its ref (-1: none yet)
+    REF       +61       byte offset of the current node  SAVE +62,63 EXEC at entry
+    R         +64,+65   reject mask / temporaries (the second temporary mask is VCC)
+"""
+import os
+import sys
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "raytracedshadows_amd", "csrc", "rts_wide_asm.inc")
+BASE = 20
+AX = "xyz"
+
+
+def s(i):
+    return f"s{BASE + i}"
+
+
+def sp(i):
+    return f"s[{BASE + i}:{BASE + i + 1}]"
+
+
+def N(i):
+    return s(i)
+
+
+def T(i):
+    return s(32 + i)
+
+
+def H(k):
+    return sp(48 + 2 * k)
+
+
+M, NXM, NXREF, REF, SAVE, R, R2 = sp(56), sp(58), s(60), s(61), sp(62), sp(64), "vcc"
+MLO, MHI = s(56), s(57)
+RLO, RHI = s(64), s(65)
+
+
+def lo(k, a):
+    return N(6 * k + a)
+
+
+def hi(k, a):
+    return N(6 * k + 3 + a)
+
+
+def far_near(k, a, octant):
+    neg = (octant >> a) & 1
+    return (lo(k, a), hi(k, a)) if neg else (hi(k, a), lo(k, a))
+
+
+def cheap_pair(ka, kb, octant):
+    """cheap slab tests of two slots, interleaved (12 temporaries): 10 VALU each."""
+    L = []
+    if octant < 8:
+        for j, k in enumerate((ka, kb)):
+            b = 6 * j
+            for i, a in enumerate(AX):
+                L.append(f"v_fma_f32 %[t{b + i}], {far_near(k, i, octant)[0]}, %[i{a}], -%[cu{a}]")
+            for i, a in enumerate(AX):
+                L.append(f"v_fma_f32 %[t{b + 3 + i}], {far_near(k, i, octant)[1]}, %[i{a}], -%[cd{a}]")
+        for j, k in enumerate((ka, kb)):
+            b = 6 * j
+            L += [f"v_min3_f32 %[t{b}], %[t{b}], %[t{b + 1}], %[t{b + 2}]",
+                  f"v_max_f32 %[t{b + 3}], %[t{b + 3}], %[t{b + 4}]",
+                  f"v_max3_f32 %[t{b + 3}], %[t{b + 3}], %[t{b + 5}], 0"]
+        for j, k in enumerate((ka, kb)):
+            b = 6 * j
+            L.append(f"v_cmp_ge_f32 {H(k)}, %[t{b}], %[t{b + 3}]")
+    else:
+        # generic: both planes against both constants; upper bounds with cu, lower bounds with cd (16 VALU per slot)
+        for k in (ka, kb):
+            for i, a in enumerate(AX):
+                L += [f"v_fma_f32 %[t{i}], {hi(k, i)}, %[i{a}], -%[cu{a}]",
+                      f"v_fma_f32 %[t{3 + i}], {lo(k, i)}, %[i{a}], -%[cu{a}]",
+                      f"v_max_f32 %[t{i}], %[t{i}], %[t{3 + i}]",
+                      f"v_fma_f32 %[t{6 + i}], {hi(k, i)}, %[i{a}], -%[cd{a}]",
+                      f"v_fma_f32 %[t{9 + i}], {lo(k, i)}, %[i{a}], -%[cd{a}]",
+                      f"v_min_f32 %[t{6 + i}], %[t{6 + i}], %[t{9 + i}]"]
+            L += ["v_min3_f32 %[t0], %[t0], %[t1], %[t2]",
+                  "v_max_f32 %[t6], %[t6], %[t7]",
+                  "v_max3_f32 %[t6], %[t6], %[t8], 0",
+                  f"v_cmp_ge_f32 {H(k)}, %[t0], %[t6]"]
+    return L
+
+
+def exact_box(k, octant, dst):
+    """the reference's slab test (comp:61-73) of slot k's box for the lanes in EXEC -> dst (SGPR pair)."""
+    L = []
+    if octant < 8:
+        for i, a in enumerate(AX):
+            L.append(f"v_sub_f32 %[t{i}], {far_near(k, i, octant)[0]}, %[o{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_sub_f32 %[t{3 + i}], {far_near(k, i, octant)[1]}, %[o{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_mul_f32 %[t{i}], %[t{i}], %[i{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_mul_f32 %[t{3 + i}], %[t{3 + i}], %[i{a}]")
+        L += ["v_min3_f32 %[t0], %[t0], %[t1], %[t2]",
+              "v_max_f32 %[t3], %[t3], %[t4]",
+              "v_max3_f32 %[t3], %[t3], %[t5], 0",
+              f"v_cmp_ge_f32 {dst}, %[t0], %[t3]"]
+    else:
+        for i, a in enumerate(AX):
+            L.append(f"v_sub_f32 %[t{i}], {hi(k, i)}, %[o{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_sub_f32 %[t{3 + i}], {lo(k, i)}, %[o{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_mul_f32 %[t{i}], %[t{i}], %[i{a}]")
+        for i, a in enumerate(AX):
+            L.append(f"v_mul_f32 %[t{3 + i}], %[t{3 + i}], %[i{a}]")
+        L += ["v_max_f32 %[t6], %[t0], %[t3]", "v_min_f32 %[t0], %[t0], %[t3]",
+              "v_max_f32 %[t3], %[t1], %[t4]", "v_min_f32 %[t1], %[t1], %[t4]",
+              "v_max_f32 %[t4], %[t2], %[t5]", "v_min_f32 %[t2], %[t2], %[t5]",
+              "v_min3_f32 %[t6], %[t6], %[t3], %[t4]",
+              "v_max_f32 %[t0], %[t0], %[t1]",
+              "v_max3_f32 %[t0], %[t0], %[t2], 0",
+              f"v_cmp_ge_f32 {dst}, %[t6], %[t0]"]
+    return L
+
+
+def triangle(dst):
+    """Moeller-Trumbore exactly as comp:41-59 spells it (separate mul/sub/add, dots left to right, correctly rounded
+    1/det: the sequence hipcc emits for 1.0f / x); v0 = T0-2, e0 = T3-5, e1 = T6-8.  dst = lanes of EXEC that are REJECTED."""
+    e0, e1, v0 = (T(3), T(4), T(5)), (T(6), T(7), T(8)), (T(0), T(1), T(2))
+    return [
+        f"v_mul_f32 %[t0], {e1[2]}, %[dy]", f"v_mul_f32 %[t1], {e1[1]}, %[dz]", "v_sub_f32 %[t0], %[t0], %[t1]",   # s1.x = d.y*e1.z - e1.y*d.z
+        f"v_mul_f32 %[t1], {e1[0]}, %[dz]", f"v_mul_f32 %[t2], {e1[2]}, %[dx]", "v_sub_f32 %[t1], %[t1], %[t2]",   # s1.y = d.z*e1.x - e1.z*d.x
+        f"v_mul_f32 %[t2], {e1[1]}, %[dx]", f"v_mul_f32 %[t3], {e1[0]}, %[dy]", "v_sub_f32 %[t2], %[t2], %[t3]",   # s1.z = d.x*e1.y - e1.x*d.y
+        f"v_mul_f32 %[t3], {e0[0]}, %[t0]", f"v_mul_f32 %[t4], {e0[1]}, %[t1]", "v_add_f32 %[t3], %[t3], %[t4]",
+        f"v_mul_f32 %[t4], {e0[2]}, %[t2]", "v_add_f32 %[t3], %[t3], %[t4]",                                       # det = dot(s1, e0)
+        f"v_div_scale_f32 %[t5], {R}, %[t3], %[t3], 1.0",
+        "v_rcp_f32 %[t7], %[t5]",
+        "v_div_scale_f32 %[t6], vcc, 1.0, %[t3], 1.0",
+        "v_fma_f32 %[t8], -%[t5], %[t7], 1.0",
+        "v_fmac_f32 %[t7], %[t8], %[t7]",
+        "v_mul_f32 %[t8], %[t6], %[t7]",
+        "v_fma_f32 %[t9], -%[t5], %[t8], %[t6]",
+        "v_fmac_f32 %[t8], %[t9], %[t7]",
+        "v_fma_f32 %[t5], -%[t5], %[t8], %[t6]",
+        "v_div_fmas_f32 %[t5], %[t5], %[t7], %[t8]",
+        "v_div_fixup_f32 %[t4], %[t5], %[t3], 1.0",                                                                # invd
+        f"v_subrev_f32 %[t5], {v0[0]}, %[ox]", f"v_subrev_f32 %[t6], {v0[1]}, %[oy]", f"v_subrev_f32 %[t7], {v0[2]}, %[oz]",   # dd = o - v0
+        "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
+        "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]",       # b1 = dot(dd, s1) * invd
+        f"v_mul_f32 %[t9], {e0[2]}, %[t6]", f"v_mul_f32 %[t10], {e0[1]}, %[t7]", "v_sub_f32 %[t9], %[t9], %[t10]",     # s2.x = dd.y*e0.z - e0.y*dd.z
+        f"v_mul_f32 %[t10], {e0[0]}, %[t7]", f"v_mul_f32 %[t11], {e0[2]}, %[t5]", "v_sub_f32 %[t10], %[t10], %[t11]",  # s2.y = dd.z*e0.x - e0.z*dd.x
+        f"v_mul_f32 %[t11], {e0[1]}, %[t5]", f"v_mul_f32 %[t12], {e0[0]}, %[t6]", "v_sub_f32 %[t11], %[t11], %[t12]",  # s2.z = dd.x*e0.y - e0.x*dd.y
+        "v_mul_f32 %[t12], %[dx], %[t9]", "v_mul_f32 %[t13], %[dy], %[t10]", "v_add_f32 %[t12], %[t12], %[t13]",
+        "v_mul_f32 %[t13], %[dz], %[t11]", "v_add_f32 %[t12], %[t12], %[t13]", "v_mul_f32 %[t12], %[t12], %[t4]",  # b2 = dot(d, s2) * invd
+        f"v_mul_f32 %[t13], {e1[0]}, %[t9]", f"v_mul_f32 %[t14], {e1[1]}, %[t10]", "v_add_f32 %[t13], %[t13], %[t14]",
+        f"v_mul_f32 %[t14], {e1[2]}, %[t11]", "v_add_f32 %[t13], %[t13], %[t14]", "v_mul_f32 %[t13], %[t13], %[t4]",  # t = dot(e1, s2) * invd
+        "v_add_f32 %[t14], %[t8], %[t12]",                                                                          # b1 + b2
+        # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51)
+        f"v_cmp_gt_f32 {dst}, 0, %[t8]",
+        f"v_cmp_lt_f32 {R2}, 1.0, %[t8]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_gt_f32 {R2}, 0, %[t12]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_lt_f32 {R2}, 1.0, %[t14]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_gt_f32 {R2}, 0, %[t13]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_lt_f32 {R2}, %[tm], %[t13]", f"s_or_b64 {dst}, {dst}, {R2}"]
+
+
+def loop(octant):
+    L = [f"s_mov_b64 {SAVE}, exec",
+         f"s_mov_b32 {REF}, 0",                                  # the root's wide node
+         f"s_andn2_b64 {M}, %[live], %[occ]",
+         "s_cbranch_scc0 90f",
+         # ---- one node --------------------------------------------------------------------------------------------
+         "1:",
+         f"s_load_dwordx16 s[{BASE}:{BASE + 15}], %[wb], {REF}",
+         f"s_load_dwordx16 s[{BASE + 16}:{BASE + 31}], %[wb], {REF} offset:64",
+         "s_cmp_gt_u32 %[sp], 60",                               # a node pushes at most 3 entries; 64 fit
+         "s_cbranch_scc1 80f",
+         f"s_mov_b32 {NXREF}, -1",
+         f"s_mov_b64 exec, {M}",
+         "s_waitcnt lgkmcnt(0)"]
+    L += cheap_pair(0, 1, octant)
+    L += cheap_pair(2, 3, octant)
+    for k in range(4):
+        L += [f"s_cmp_lg_u64 {H(k)}, 0",
+              f"s_cbranch_scc0 2{k}f",
+              f"s_bitcmp1_b32 {N(24 + k)}, 0",
+              f"s_cbranch_scc1 3{k}f",                          # leaf slot (out of line)
+              f"s_cmp_eq_u32 {NXREF}, -1",
+              f"s_cbranch_scc0 4{k}f",                          # a next node is chosen already: push (out of line)
+              f"s_mov_b32 {NXREF}, {N(24 + k)}",
+              f"s_mov_b64 {NXM}, {H(k)}",
+              f"2{k}:"]
+    L += [f"s_cmp_eq_u32 {NXREF}, -1",
+          "s_cbranch_scc1 5f",
+          f"s_mov_b32 {REF}, {NXREF}",
+          f"s_andn2_b64 {M}, {NXM}, %[occ]",
+          "s_cbranch_scc1 1b",
+          # ---- pop -----------------------------------------------------------------------------------------------
+          "5:",
+          "s_cmp_eq_u32 %[sp], 0",
+          "s_cbranch_scc1 90f",
+          "s_sub_u32 %[sp], %[sp], 1",
+          "s_mov_b32 m0, %[sp]",
+          f"v_readlane_b32 {REF}, %[vref], m0",
+          f"v_readlane_b32 {MLO}, %[vlo], m0",
+          f"v_readlane_b32 {MHI}, %[vhi], m0",
+          f"s_andn2_b64 {M}, {M}, %[occ]",
+          "s_cbranch_scc0 5b",
+          # coherence statistics at pops: members picked up against rays alive (dissolve rule)
+          f"s_bcnt1_i32_b64 {RLO}, {M}",
+          f"s_add_u32 %[acc], %[acc], {RLO}",
+          "s_sub_u32 %[budget], %[budget], 1",
+          "s_cbranch_scc0 1b",
+          f"s_andn2_b64 {R}, %[live], %[occ]",
+          f"s_bcnt1_i32_b64 {RLO}, {R}",
+          f"s_mul_i32 {RLO}, {RLO}, %[thr]",                     # alive * window * share
+          f"s_lshl_b32 {RHI}, %[acc], 4",                        # picked up * 16
+          "s_mov_b32 %[acc], 0",
+          "s_mov_b32 %[budget], %[window]",
+          f"s_cmp_lt_u32 {RHI}, {RLO}",
+          "s_cbranch_scc0 1b",                                   # coherent enough: go on
+          # ---- dissolve: the current node goes back on the stack, every ray continues alone ----------------------------
+          "80:",
+          "s_mov_b32 m0, %[sp]",
+          f"v_writelane_b32 %[vref], {REF}, m0",
+          f"v_writelane_b32 %[vlo], {MLO}, m0",
+          f"v_writelane_b32 %[vhi], {MHI}, m0",
+          "s_add_u32 %[sp], %[sp], 1",
+          "s_mov_b32 %[st], 1",
+          "s_branch 99f",
+          "90:",
+          "s_mov_b32 %[st], 0",
+          "s_branch 99f"]
+    # ---- out of line: push slot k ----------------------------------------------------------------------------------
+    for k in range(4):
+        L += [f"4{k}:",
+              "s_mov_b32 m0, %[sp]",
+              f"v_writelane_b32 %[vref], {N(24 + k)}, m0",
+              f"v_writelane_b32 %[vlo], {s(48 + 2 * k)}, m0",
+              f"v_writelane_b32 %[vhi], {s(49 + 2 * k)}, m0",
+              "s_add_u32 %[sp], %[sp], 1",
+              f"s_branch 2{k}b"]
+    # ---- out of line: leaf slot k ------------------------------------------------------------------------------------
+    for k in range(4):
+        L += [f"3{k}:",
+              # an EMPTY slot (ref END, inverted box) can "hit" in the generic form, which takes max/min of both planes
+              # whatever their order; END - 1 must never reach the load below
+              f"s_cmp_eq_u32 {N(24 + k)}, -1",
+              f"s_cbranch_scc1 2{k}b",
+              # the rays that hit this slot's box and are not occluded yet.  (Decided BEFORE the record is requested: scalar
+              #  loads return in any order, so a request that nobody waits for could land in T after a later handler's.)
+              f"s_andn2_b64 exec, {H(k)}, %[occ]",
+              f"s_cbranch_scc0 6{k}f",
+              f"s_sub_u32 {REF}, {N(24 + k)}, 1",               # (REF is free here: the node is in registers)
+              f"s_load_dwordx16 s[{BASE + 32}:{BASE + 47}], %[tb], {REF}",
+              "s_waitcnt lgkmcnt(0)"]
+        L += triangle(R)
+        L += [f"s_andn2_b64 exec, exec, {R}",                   # lanes whose ray hits the triangle
+              f"s_cbranch_scc0 6{k}f"]
+        L += exact_box(k, octant, R)                             # ... count iff the ray reaches the leaf: exact test of its parent's box
+        L += [f"s_or_b64 %[occ], %[occ], {R}",
+              f"6{k}:",
+              f"s_branch 2{k}b"]
+    L += ["99:",
+          "s_waitcnt lgkmcnt(0)",                                # nothing of ours may land in SGPRs after the asm ends
+          f"s_mov_b64 exec, {SAVE}"]
+    return L
+
+
+def emit(octant, ind):
+    lines = loop(octant)
+    body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
+    outs = ['[sp] "+s"(sp)', '[acc] "+s"(acc)', '[budget] "+s"(budget)', '[occ] "+s"(occ)', '[st] "=&s"(st)',
+            '[vref] "+v"(stRef)', '[vlo] "+v"(stLo)', '[vhi] "+v"(stHi)']
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(15)]
+    ins = ['[wb] "s"(wbase)', '[tb] "s"(tbase)', '[live] "s"(live)', '[thr] "s"(thr)', '[window] "s"(window)']
+    ins += [f'[o{a}] "v"(r.o.{a})' for a in AX] + [f'[i{a}] "v"(r.inv.{a})' for a in AX] + [f'[d{a}] "v"(r.d.{a})' for a in AX]
+    ins += ['[tm] "v"(r.tmax)']
+    ins += [f'[cu{a}] "v"(w.cU.{a})' for a in AX] + [f'[cd{a}] "v"(w.cD.{a})' for a in AX]
+    clob = [f'"s{i}"' for i in range(BASE, BASE + 66)] + ['"vcc"', '"scc"', '"m0"']
+    return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
+            f"{ind}    : {', '.join(clob)});\n")
+
+
+def main():
+    o = ["// GENERATED by tools/gen_wide_asm.py -- do not edit by hand.",
+         "// The loop of the wide packet kernel (see rts_kernels.hip, 'V_WIDE').  Walks the private wide nodes from the root with",
+         "// the stack in stRef/stLo/stHi (entry i in lane i).  Returns 0 when the packet is finished and 1 when it dissolves",
+         "// (too few members per popped node, or the stack nearly full): every pending (node, members) is on the stack then.",
+         "// form 0..7: ordered slab tests for the sign octant (bit a set <=> 1/d component a negative in every lane); 8: generic.",
+         "",
+         "__device__ __forceinline__ uint32_t wideDescend(uint32_t form, const void* wbase, const void* tbase, const Ray& r,",
+         "                                              const WideRay& w, uint64_t live, uint64_t& occ, uint32_t& sp,",
+         "                                              uint32_t& stRef, uint32_t& stLo, uint32_t& stHi, uint32_t window, uint32_t thr) {",
+         "    uint32_t st, acc = 0;",
+         "    int32_t budget = (int32_t)window - 1;",
+         "    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;",
+         "    switch (form) {"]
+    for octant in range(9):
+        o.append(f"    case {octant}:" if octant < 8 else "    default:")
+        o.append(emit(octant, "        ").rstrip("\n"))
+        o.append("        break;")
+    o += ["    }", "    return st;", "}", ""]
+    open(OUT, "w").write("\n".join(o))
+    print("wrote", OUT, sum(1 for _ in open(OUT)), "lines")
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--config", default="atrium_1080p")
     ap.add_argument("--shares", default="4")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--kernel", type=int, default=3)
     args = ap.parse_args()
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config)
@@ -26,7 +27,7 @@ def main():
         d_pos = ctx.malloc(wl.positions.nbytes)
         d_mask = ctx.malloc(W * H)
         ctx.h2d(d_pos, wl.positions)
-        ctx.set_option("kernel", 3)
+        ctx.set_option("kernel", args.kernel)
         waves = ((W + 7) // 8) * ((H + 7) // 8)
         for share in [int(s) for s in args.shares.split(",")]:
             ctx.set_option("packet_share", share)
