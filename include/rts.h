@@ -66,13 +66,19 @@ typedef struct rts_ray { float o[4]; float d[4]; } rts_ray;
  *   point : o0 = cam + rel; bias as comp:138-140; dn = (L-o0)/|L-o0|; o = o0 + dn*bias;
  *           d = L - o (un-normalised); tmax = 1
  *   nsamples in [2,64]: sample j uses L + offsets[j].xyz; the output byte is the number of
- *   UNoccluded samples (0..nsamples) instead of 0/1. */
+ *   UNoccluded samples (0..nsamples) instead of 0/1.  `table` != 0: per-pixel jitter, see the field. */
 enum { RTS_LIGHT_DIRECTIONAL = 0, RTS_LIGHT_POINT = 1 };
 typedef struct rts_light {
     uint32_t type;
     uint32_t nsamples;      /* 0 or 1 = hard shadow */
     float    xyz[3];
-    float    reserved;
+    uint32_t table;         /* 0: sample j uses offsets[j] in every pixel (one coherent pass per sample).
+                               T in [nsamples, 64]: PER-PIXEL jitter -- offsets[] holds T entries and pixel p = y*W + x of the
+                               frame uses offsets[(start(p) + j) mod T], start(p) = (hash32(p) * T) >> 32 with
+                               hash32(v): v ^= v >> 16; v *= 0x7feb352d; v ^= v >> 15; v *= 0x846ca68b; v ^= v >> 16
+                               (32-bit wrap-around): integer arithmetic only, the same on every device and in every
+                               stripe.  Neighbouring pixels then aim at different points of the light in the same pass,
+                               which is what stresses ray packets (BASELINE configs[4]).  (The field was `reserved`, 0.) */
     float    offsets[64][4];
 } rts_light;
 

@@ -269,13 +269,25 @@ static inline float max3abs(V3 v) { return gmax(gmax(fabsf(v.x), fabsf(v.y)), fa
 //   type 1: point light at xyz (extension, BASELINE.json configs 2-5):
 //           o0 = cam+rel; bias as comp:138-140; dn = (L-o0)/|L-o0|; o = o0 + dn*bias; d = L-o; tmax = 1
 //   nsamples>1: sample j uses light xyz + offsets[j]; output = number of UNoccluded samples.
-struct OLight { u32 type; u32 nsamples; float xyz[3]; float pad; float offsets[64][4]; };
+//   table != 0 (include/rts.h, rts_light.table): per-pixel jitter -- pixel p starts at entry (hash32(p) * table) >> 32
+//           of a table of `table` offsets and takes nsamples consecutive entries (mod table).  Integers only.
+struct OLight { u32 type; u32 nsamples; float xyz[3]; u32 table; float offsets[64][4]; };
 
-static inline void genRay(const float* cam, V3 rel, const OLight& lt, u32 j, V3* o, float* tmax, V3* d) {
+static inline u32 pixelHash(u32 v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+static inline u32 tableEntry(const OLight& lt, u32 j, u32 pixel) {
+    if (lt.table == 0) return j;
+    const u32 start = (u32)(((uint64_t)pixelHash(pixel) * lt.table) >> 32);
+    return (start + j) % lt.table;
+}
+
+static inline void genRay(const float* cam, V3 rel, const OLight& lt, u32 j, V3* o, float* tmax, V3* d, u32 pixel = 0) {
     V3 origin = { cam[0] + rel.x, cam[1] + rel.y, cam[2] + rel.z };                  // comp:136
     float bias = gmax(epsilonFor(max3abs(origin), 13), epsilonFor(max3abs(rel), 13)); // comp:138-140
     V3 L = { lt.xyz[0], lt.xyz[1], lt.xyz[2] };
-    if (lt.nsamples > 1) { L.x = L.x + lt.offsets[j][0]; L.y = L.y + lt.offsets[j][1]; L.z = L.z + lt.offsets[j][2]; }
+    if (lt.nsamples > 1) { const u32 e = tableEntry(lt, j, pixel); L.x = L.x + lt.offsets[e][0]; L.y = L.y + lt.offsets[e][1]; L.z = L.z + lt.offsets[e][2]; }
     if (lt.type == 0) {
         origin.x = origin.x + L.x * bias; origin.y = origin.y + L.y * bias; origin.z = origin.z + L.z * bias; // comp:143
         *o = origin; *tmax = 1e9f; *d = L;                                            // comp:145-146
@@ -416,7 +428,7 @@ void orc_shadow_mask(const uint32_t* packed, const float* constants, const void*
             u32 lit = 0, pv = 0, pl = 0;
             for (u32 j = 0; j < ns; ++j) {
                 V3 o, d; float tmax;
-                genRay(constants, rel, lt, j, &o, &tmax, &d);
+                genRay(constants, rel, lt, j, &o, &tmax, &d, (u32)pix);
                 u32 v, l;
                 lit += anyHit(packed, o, tmax, d, &v, &l) ? 0 : 1;                         // comp:148
                 pv += v; pl += l;
@@ -438,7 +450,7 @@ void orc_gen_rays(const float* constants, const void* light_v, const float* posi
         V3 rel = { positions[p * 4 + 0], positions[p * 4 + 1], positions[p * 4 + 2] };
         for (u32 j = 0; j < ns; ++j) {
             V3 o, d; float tmax;
-            genRay(constants, rel, lt, j, &o, &tmax, &d);
+            genRay(constants, rel, lt, j, &o, &tmax, &d, (u32)p);
             float* r = rays + (p * ns + j) * 8;
             r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = tmax; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = 0.0f;
         }

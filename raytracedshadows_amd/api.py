@@ -73,12 +73,14 @@ class RayTracingConstants(C.Structure):
 class Light(C.Structure):
     """``rts_light``: directional (the reference) / point light, 1..64 samples."""
     _fields_ = [("type", C.c_uint32), ("nsamples", C.c_uint32), ("xyz", C.c_float * 3),
-                ("reserved", C.c_float), ("offsets", (C.c_float * 4) * 64)]
+                ("table", C.c_uint32), ("offsets", (C.c_float * 4) * 64)]
     DIRECTIONAL = 0
     POINT = 1
 
     @classmethod
-    def make(cls, kind, xyz, offsets=None):
+    def make(cls, kind, xyz, offsets=None, nsamples=None):
+        """offsets: the sample offsets (<= 64).  nsamples < len(offsets): PER-PIXEL jitter -- every pixel takes `nsamples`
+        consecutive entries of the table from a start hashed from its index (``rts_light.table``, include/rts.h)."""
         lt = cls()
         lt.type = kind
         for i in range(3):
@@ -87,6 +89,8 @@ class Light(C.Structure):
         if offsets is not None:
             offsets = np.asarray(offsets, dtype=np.float32)
             lt.nsamples = offsets.shape[0]
+            if nsamples is not None and nsamples != offsets.shape[0]:
+                lt.nsamples, lt.table = nsamples, offsets.shape[0]
             for j in range(offsets.shape[0]):
                 for i in range(3):
                     lt.offsets[j][i] = offsets[j, i]

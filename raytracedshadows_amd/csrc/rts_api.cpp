@@ -45,6 +45,8 @@ struct rts_ctx {
     bool bvhEnclosed = false;                // pre-order binary tree whose boxes enclose their children's (validateKernel)
     int wideCopy = 1;                        // option "wide_copy": build the private copy at upload
     int wideLane = 1;                        // option "wide_lane": dissolved wide packets walk the wide nodes lane per ray
+    int softSplit = 1;                       // option "soft_split": soft shadows with 4 waves per tile (samples side by side)
+    uint32_t pixelBase = 0;                  // set around a host-pointer stripe (see rts_trace_shadow_mask)
 };
 
 namespace {
@@ -86,6 +88,8 @@ int fillParams(rts_ctx* ctx, TraceParams& p) {
     p.wideBytes = (uint32_t)((size_t)ctx->P * 192u);
     p.trisOffset = (uint32_t)((size_t)ctx->P * 128u);
     p.wideLane = (uint32_t)ctx->wideLane;
+    p.softSplit = (uint32_t)ctx->softSplit;
+    p.pixelBase = ctx->pixelBase;
     return RTS_OK;
 }
 
@@ -246,6 +250,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "wide_copy")) { c->wideCopy = value ? 1 : 0; return RTS_OK; }      // takes effect at the next upload / build
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
@@ -273,6 +278,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "bvh_enclosed")) { *value = c->bvhEnclosed ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "wide_copy")) { *value = c->wideCopy; return RTS_OK; }
     if (!strcmp(key, "wide_lane")) { *value = c->wideLane; return RTS_OK; }
+    if (!strcmp(key, "soft_split")) { *value = c->softSplit; return RTS_OK; }
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
     if (!strcmp(key, "wide_levels")) { *value = (int)c->wideLevels; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
@@ -284,6 +290,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (!c || !k || !d_positions || !d_mask || W == 0 || H == 0 || row_begin > row_end || row_end > H)
         return RTS_ERR_INVALID_ARG;
     if (light && (light->type > RTS_LIGHT_POINT || light->nsamples > 64)) return RTS_ERR_INVALID_ARG;
+    if (light && light->table && (light->table > 64 || light->table < light->nsamples || light->nsamples < 2)) return RTS_ERR_INVALID_ARG;
     if ((uint64_t)W * H > (1ull << 31)) return RTS_ERR_INVALID_ARG;      // tile counts are 32-bit on the device
     TraceParams p;
     int s = fillParams(c, p);
@@ -315,7 +322,11 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.nBlocks = p.blocksX * p.blocksY;
     p.swizzle = c->swizzle ? 1u : 0u;
     p.gridBlocks = p.swizzle ? ((p.nBlocks + 7) / 8) * 8 : p.nBlocks;
-    if (c->d_waveStats && (size_t)p.gridBlocks * c->blockWaves * 32 <= c->waveStatsBytes) {
+    // (soft shadows in the one-tile packet forms run 4 waves per workgroup: "soft_split")
+    const bool split = light && light->nsamples > 1 && c->softSplit && c->blockWaves == 1 &&
+                       (variant == rts::V_PACKET || variant == rts::V_WIDE);
+    const size_t statWaves = split ? 4 : (size_t)c->blockWaves;
+    if (c->d_waveStats && (size_t)p.gridBlocks * statWaves * 32 <= c->waveStatsBytes) {
         p.waveStats = c->d_waveStats;
         p.waveRealtime = c->d_waveStats + c->waveStatsBytes / 8;
     }
@@ -327,7 +338,8 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.lightType = light->type;
         p.nsamples = light->nsamples > 1 ? light->nsamples : 1;
         for (int i = 0; i < 3; ++i) p.light[i] = light->xyz[i];
-        if (p.nsamples > 1) memcpy(p.offsets, light->offsets, sizeof(float) * 4 * p.nsamples);
+        p.lightTable = p.nsamples > 1 ? light->table : 0u;
+        if (p.nsamples > 1) memcpy(p.offsets, light->offsets, sizeof(float) * 4 * (p.lightTable ? p.lightTable : p.nsamples));
     } else {
         p.lightType = RTS_LIGHT_DIRECTIONAL;
         p.nsamples = 1;
@@ -372,7 +384,9 @@ int rts_trace_shadow_mask(rts_ctx* c, const rts_constants* k, const rts_light* l
     if (s == RTS_OK) s = ensure(&c->d_out, &c->outBytes, outB);
     if (s != RTS_OK) return s;
     RTS_HIP(hipMemcpy(c->d_in, positions + (size_t)row_begin * W * 4, inB, hipMemcpyHostToDevice));
+    c->pixelBase = row_begin * W;          // per-pixel jitter hashes the pixel's index in the caller's frame
     s = rts_trace_shadow_mask_device(c, k, light, (const float*)c->d_in, W, rows, 0, rows, (uint8_t*)c->d_out, nullptr);
+    c->pixelBase = 0;
     if (s != RTS_OK) return s;
     RTS_HIP(hipMemcpy(mask + (size_t)row_begin * W, c->d_out, outB, hipMemcpyDeviceToHost));
     return RTS_OK;

@@ -37,6 +37,9 @@ struct TraceParams {
     uint32_t rowOrder;          // dispatch order of the tile rows (speed only): 0 first to last, 1 last to first, 2 middle row outwards
     float cam[3];
     uint32_t lightType, nsamples;
+    uint32_t softSplit;         // soft shadows: 4 waves per tile, samples dealt over them (option "soft_split")
+    uint32_t pixelBase;         // index in the caller's frame of this dispatch's pixel 0 (host-pointer stripes travel as frames of their own)
+    uint32_t lightTable;        // per-pixel jitter: entries of offsets[] a pixel starts in (0 = off); rts_light.table
     float light[3];
     // generic rays
     const void* rays;         // rts_ray[n] (device)

@@ -85,14 +85,26 @@ __device__ __forceinline__ bool finite3(F3 v) {
 }
 
 // comp:128-146 (+ the point-light / multi-sample extensions documented in include/rts.h)
-__device__ __forceinline__ Ray makeShadowRay(const TraceParams& p, F3 rel, uint32_t sample) {
+// rts_light.table (include/rts.h): where in the offset table the pixel starts
+__device__ __forceinline__ uint32_t hash32(uint32_t v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+__device__ __forceinline__ uint32_t sampleIndex(const TraceParams& p, uint32_t sample, uint32_t pixel) {
+    if (p.lightTable == 0) return sample;
+    const uint32_t j = __umulhi(hash32(pixel + p.pixelBase), p.lightTable) + sample;   // start < table, sample < nsamples <= table
+    return j >= p.lightTable ? j - p.lightTable : j;
+}
+
+__device__ __forceinline__ Ray makeShadowRay(const TraceParams& p, F3 rel, uint32_t sample, uint32_t pixel = 0) {
     F3 origin{ p.cam[0] + rel.x, p.cam[1] + rel.y, p.cam[2] + rel.z };
     float mo = gmax(gmax(__builtin_fabsf(origin.x), __builtin_fabsf(origin.y)), __builtin_fabsf(origin.z));
     float mr = gmax(gmax(__builtin_fabsf(rel.x), __builtin_fabsf(rel.y)), __builtin_fabsf(rel.z));
     float bias = gmax(epsilonFor(mo, 13), epsilonFor(mr, 13));
     F3 L{ p.light[0], p.light[1], p.light[2] };
     if (p.nsamples > 1) {
-        L.x = L.x + p.offsets[sample][0]; L.y = L.y + p.offsets[sample][1]; L.z = L.z + p.offsets[sample][2];
+        const uint32_t j = sampleIndex(p, sample, pixel);
+        L.x = L.x + p.offsets[j][0]; L.y = L.y + p.offsets[j][1]; L.z = L.z + p.offsets[j][2];
     }
     Ray r;
     if (p.lightType == 0) {
@@ -987,7 +999,7 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
     const uint32_t ns = p.nsamples > 1 ? p.nsamples : 1u;
     uint32_t lit = 0;
     for (uint32_t s = 0; s < ns; ++s) {
-        Ray r = makeShadowRay(p, rel, s);
+        Ray r = makeShadowRay(p, rel, s, (uint32_t)pix);
         bool unsafe = live && !raySafe(r);
         bool occluded;
         if (p.bvhFinite && __builtin_amdgcn_ballot_w64(unsafe) == 0)
@@ -1007,18 +1019,23 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // PLAIN = the everyday launch (natural tile order on a 2-D grid, one contiguous row range, no diagnostics): the scalar
 // prologue that sorts out the other cases is compiled away.
 // WIDE = the walk over the private wide nodes (K = 1, WPB = 1): 1 = the loop in assembly, 2 = the same loop compiled.
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
+// SPLIT (soft shadows, K = 1, WPB = 1): SPLIT waves per workgroup work on the SAME 8x8 tile, wave w walks samples w,
+// w + SPLIT, ...; the counts meet in LDS and wave 0 stores the byte.  A pixel's samples then run side by side instead of
+// one after the other: a wave lives 1/SPLIT as long (shorter tail, finer-grained stripes).
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1>
+__global__ __launch_bounds__(64 * WPB * SPLIT) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[WPB][64];     // lane numbers exchanged by traverseShare (256 B per wave)
+    static_assert(SPLIT == 1 || (K == 1 && WPB == 1 && SOFT), "samples are split over waves in the one-tile soft-shadow form only");
+    __shared__ uint32_t shareSlots[WPB * SPLIT][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
-    __shared__ uint32_t laneStacks[WIDE != 0 ? WPB : 1][WIDE != 0 ? LANE_STACK * 64 : 1];   // per-lane stacks of the wide lane walk (4 KB per wave)
+    __shared__ uint32_t laneStacks[WIDE != 0 ? WPB * SPLIT : 1][WIDE != 0 ? LANE_STACK * 64 : 1];   // per-lane stacks of the wide lane walk (4 KB per wave)
     uint32_t* laneStack = WIDE != 0 ? laneStacks[threadIdx.x >> 6] : nullptr;
+    __shared__ uint32_t partial[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 64 : 1];                          // per-wave counts of unoccluded samples
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx = blockIdx.x, by = dispatchRow(p, blockIdx.y);       // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);
+    const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);     // (SPLIT: every wave, the same tile)
     const uint32_t v0 = (WPB == 4 ? by * (2u * TH) + (wave >> 1) * TH : by * TH) + (lane >> 3);
     bool live[K];
     size_t pix[K];
@@ -1046,12 +1063,12 @@ void shadowMaskPacketKernel(TraceParams p) {
 #pragma unroll
     for (int k = 0; k < K; ++k) lit[k] = 0;
     uint64_t tReady = 0;
-    for (uint32_t s = 0; s < ns; ++s) {
+    for (uint32_t s = SPLIT > 1 ? wave : 0u; s < ns; s += SPLIT) {
         Ray r[K];
         bool occluded[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s);
-        if (!PLAIN && p.waveStats && s == 0) {       // diagnostics: the G-buffer texel is in and the first ray exists
+        for (int k = 0; k < K; ++k) r[k] = makeShadowRay(p, rel[k], s, (uint32_t)pix[k]);
+        if (!PLAIN && p.waveStats && s < SPLIT) {    // diagnostics: the G-buffer texel is in and the first ray exists
             asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
             tReady = __builtin_amdgcn_s_memtime();
         }
@@ -1062,11 +1079,22 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
     // (8-byte row stores built from a ballot were tried: WRITE_SIZE stayed at 40 MB per 8.3 MB mask -- the
     // memory side counts 32-byte sectors either way -- and the kernel got 10 % slower; byte stores stay.)
+    if constexpr (SPLIT > 1) {
+        partial[wave][lane] = lit[0];
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);       // comp:150
+            for (int w = 0; w < SPLIT; ++w) sum += partial[w][lane];
+            if (live[0]) __builtin_nontemporal_store((uint8_t)sum, &p.mask[pix[0]]);     // comp:150
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
+    }
     if (!PLAIN && p.waveStats && lane == 0) {    // diagnostics: never read by any kernel, never part of an output
-        const size_t slot = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave;
+        const size_t slot = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WPB * SPLIT) + wave;
         uint64_t* o = p.waveStats + slot * 4;
         o[0] = tStart;
         o[1] = __builtin_amdgcn_s_memtime();
@@ -1155,7 +1183,8 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     }
     if (variant == V_WIDE) {
         dim3 b1(64);
-        if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
+        if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1, 4>), grid, dim3(256), 0, stream, p);
+        else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1>), grid, b1, ldsPad, stream, p);
         else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 1>), grid, b1, ldsPad, stream, p);
@@ -1171,7 +1200,8 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         dim3 b1(64);
         switch (variant) {
         case V_PACKET:
-            if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
+            if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 0, 4>), grid, dim3(256), 0, stream, p);
+            else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
             else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);

@@ -21,6 +21,8 @@ CONFIGS = {
     "courtyard_4k_soft16": ("courtyard", 3840, 2160, "point", 16),
     "city_4k_soft16_wide": ("city", 3840, 2160, "point", 16),  # configs[4] with a five times larger light (SOFT_RADIUS)
     "city_4k_directional": ("city", 3840, 2160, "directional", 1),   # the reference's own light (RayTracedShadows.cpp:245, comp:128-151) at the headline size
+    "city_4k_soft16_pp": ("city", 3840, 2160, "point", 16),    # configs[4] as a ray-packet STRESS: per-pixel jitter (PER_PIXEL_TABLE)
+    "courtyard_4k_soft16_pp": ("courtyard", 3840, 2160, "point", 16),
     "calib_4k": ("calib", 3840, 2160, "point", 1),            # counter calibration only (see scenes.calib)
 }
 
@@ -28,12 +30,16 @@ CONFIGS = {
 #: radius of the jittered light as a fraction of the scene's diagonal (default 1 %)
 SOFT_RADIUS = {"city_4k_soft16_wide": 0.05}
 
+#: configs whose light is a table of this many offsets from which every pixel takes `spp` entries, starting at a position
+#: hashed from the pixel index (rts_light.table): neighbouring pixels aim at different points of the light in the same pass
+PER_PIXEL_TABLE = {"city_4k_soft16_pp": 64, "courtyard_4k_soft16_pp": 64}
+
 
 class Workload:
     pass
 
 
-def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None, packed=None, radius=0.01):
+def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log=None, packed=None, radius=0.01, table=0):
     say = log or (lambda *a: None)
     wl = Workload()
     t0 = time.time()
@@ -71,10 +77,10 @@ def prepare(scene_name, W, H, light="point", spp=1, via_obj=True, threads=0, log
     wl.nodes = nodes
     wl.positions = positions
     wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
-    return relight(wl, light, spp, radius)
+    return relight(wl, light, spp, radius, table)
 
 
-def relight(wl, light="point", spp=1, radius=0.01):
+def relight(wl, light="point", spp=1, radius=0.01, table=0):
     """The same scene, camera and G-buffer under another light / sample count (a shallow copy of `wl`)."""
     import copy
     wl = copy.copy(wl)
@@ -86,7 +92,8 @@ def relight(wl, light="point", spp=1, radius=0.01):
     else:
         r = radius * float(np.linalg.norm(sc.bbox_max - sc.bbox_min))
         wl.light = api.Light.make(api.Light.POINT, sc.light_point,
-                                  scenes.jitter_offsets(spp, r) if spp > 1 else None)
+                                  scenes.jitter_offsets(max(spp, table), r) if spp > 1 else None,
+                                  nsamples=spp if spp > 1 else None)
     wl.rays = wl.W * wl.H * max(1, spp)
     return wl
 
@@ -97,8 +104,9 @@ def prepare_config(name, cache=False, **kw):
     passes of bench.py (child processes of one run) do not rebuild them."""
     scene, W, H, light, spp = CONFIGS[name]
     radius = SOFT_RADIUS.get(name, 0.01)
+    table = PER_PIXEL_TABLE.get(name, 0)
     if not cache:
-        return prepare(scene, W, H, light=light, spp=spp, radius=radius, **kw)
+        return prepare(scene, W, H, light=light, spp=spp, radius=radius, table=table, **kw)
     import hashlib
     h = hashlib.sha256()
     h.update(repr((name, scene, W, H)).encode())
@@ -121,10 +129,10 @@ def prepare_config(name, cache=False, **kw):
             sc = wl.scene
             wl.constants = api.RayTracingConstants.make(sc.eye, sc.light_direction, W, H, sc.target - sc.eye)
             say(f"workload {name} loaded from {path}")
-            return relight(wl, light, spp, radius)
+            return relight(wl, light, spp, radius, table)
         except Exception as e:                       # a torn or stale file: rebuild
             say(f"cache {path} unusable ({e!r}); rebuilding")
-    wl = prepare(scene, W, H, light=light, spp=spp, radius=radius, **kw)
+    wl = prepare(scene, W, H, light=light, spp=spp, radius=radius, table=table, **kw)
     tmp = f"{path}.{os.getpid()}.tmp.npz"
     np.savez(tmp, vertices=wl.vertices, indices=wl.indices, packed=wl.packed, positions=wl.positions,
              build_seconds=np.float64(wl.build_seconds))

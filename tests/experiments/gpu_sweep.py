@@ -38,7 +38,8 @@ def main():
             light, spp = "point", 1
         else:
             scene, W, H, light, spp = workloads.CONFIGS[cfg]
-        wl = workloads.prepare(scene, W, H, light="directional" if args.directional else light, spp=spp, log=print)
+        wl = workloads.prepare(scene, W, H, light="directional" if args.directional else light, spp=spp, log=print,
+                               radius=workloads.SOFT_RADIUS.get(cfg, 0.01), table=workloads.PER_PIXEL_TABLE.get(cfg, 0))
         t0 = time.time()
         want, V, L = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
                                         oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)

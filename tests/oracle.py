@@ -46,7 +46,7 @@ _o.orc_primary_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float
 
 class OLight(C.Structure):
     """Same layout as rts_light (include/rts.h)."""
-    _fields_ = [("type", C.c_uint32), ("nsamples", C.c_uint32), ("xyz", C.c_float * 3), ("pad", C.c_float),
+    _fields_ = [("type", C.c_uint32), ("nsamples", C.c_uint32), ("xyz", C.c_float * 3), ("table", C.c_uint32),
                 ("offsets", (C.c_float * 4) * 64)]
 
 
@@ -54,7 +54,8 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_light(kind, xyz, offsets=None):
+def make_light(kind, xyz, offsets=None, nsamples=None):
+    """offsets: the sample offsets; nsamples < len(offsets) = per-pixel jitter over the whole table (rts_light.table)."""
     lt = OLight()
     lt.type = kind
     lt.nsamples = 1
@@ -63,6 +64,8 @@ def make_light(kind, xyz, offsets=None):
     if offsets is not None:
         offsets = np.asarray(offsets, np.float32)
         lt.nsamples = offsets.shape[0]
+        if nsamples is not None and nsamples != offsets.shape[0]:
+            lt.nsamples, lt.table = nsamples, offsets.shape[0]
         for j in range(offsets.shape[0]):
             for i in range(3):
                 lt.offsets[j][i] = offsets[j, i]

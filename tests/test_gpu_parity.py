@@ -183,6 +183,44 @@ def test_config4_city_4k_16_samples_full_size(ctx, city4k):
     ctx.set_option("kernel", -1)
 
 
+def test_config4_per_pixel_jitter_every_kernel_and_stripes(ctx):
+    """rts_light.table (per-pixel jitter, BASELINE configs[4] as a packet stress): every pixel takes its 16 samples from a
+    64-entry table starting at a position hashed from its index.  Every kernel, a ragged frame, stripes (the start depends
+    on the pixel's index in the FRAME, not in the stripe); with table == nsamples the start only permutes the samples, so
+    the count equals the unjittered one."""
+    wl = workloads.prepare("city", 483, 271, spp=16, table=64)
+    assert wl.light.table == 64 and wl.light.nsamples == 16
+    want = _check_workload(ctx, wl)
+    plain = workloads.relight(wl, "point", 16)
+    base, _, _ = oracle.shadow_mask(plain.packed, plain.constants.as_array(), oracle.light_from_product(plain.light, plain.constants),
+                                    plain.positions, plain.W, plain.H)
+    assert (want != base).sum() > 1000                                              # other samples, other penumbra counts
+    rot = workloads.relight(wl, "point", 16)
+    rot.light.table = 16                                                            # start in the same 16 entries: a permutation
+    got = _check_workload(ctx, rot, variants=[-1, 0, 3, 8])
+    assert (got == base).all()
+    ctx.set_option("kernel", -1)
+    for n in (2, 5):
+        out = np.full((wl.H, wl.W), 99, np.uint8)
+        for r in range(n):
+            for b, e in partition.stripe_rows(wl.H, n, r, 16, True):
+                ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=wl.light, row_begin=b, row_end=e, out=out)
+        assert (out == want).all()
+    bad = api.Light.make(api.Light.POINT, wl.scene.light_point, scenes.jitter_offsets(8, 1.0), nsamples=16)
+    bad.table = 8                                                                   # a table smaller than the sample count
+    with pytest.raises(api.RtsError):
+        ctx.trace_shadow_mask(wl.constants, wl.positions, wl.W, wl.H, light=bad)
+
+
+def test_config4_city_4k_16_samples_per_pixel_jitter_full_size(ctx, city4k):
+    """configs[4] as the packet STRESS it is meant to be, at its own size (3840x2160 x 16 samples out of a 64-entry
+    table per pixel): the default kernel, the lane-per-ray kernel and both packet families."""
+    wl = workloads.relight(city4k, "point", 16, table=64)
+    want = _check_workload(ctx, wl, variants=[-1, 7, 3, 8])
+    assert want.max() == 16 and ((want > 0) & (want < 16)).sum() > 10000
+    ctx.set_option("kernel", -1)
+
+
 def test_config3_row_stripes_equal_full_frame(ctx):
     """configs[3] on one device: the 2/4/8 stripe sets traced one after the other reproduce the frame."""
     wl = workloads.prepare("atrium", 960, 540)

@@ -242,3 +242,36 @@ def test_ties_by_triangle_id_is_the_same_builder_where_no_centroids_tie():
     packed = oracle.bvh_build(z, 3, np.arange(12, dtype=np.uint32), 4, ties_by_prim=True)
     leaves = [int(x) - 14 for x in packed[0:14:2, 3] if x != 0xFFFFFFFF]
     assert leaves == [0, 1, 2, 3]                       # x centroids +0, -0, -0, +0 compare equal: triangle order decides
+
+
+def test_per_pixel_jitter_hash_known_answers_and_permutation_property():
+    """rts_light.table: the start of a pixel in the offset table is (hash32(p) * T) >> 32 with the documented integer hash
+    (known answers of the hash as pinned values; the oracle's rays are checked against them below); with T == nsamples the start only permutes the samples, so the
+    count of unoccluded samples is the unjittered one; with a larger table other samples are taken."""
+    def hash32(v):
+        v &= 0xFFFFFFFF
+        v ^= v >> 16; v = (v * 0x7feb352d) & 0xFFFFFFFF
+        v ^= v >> 15; v = (v * 0x846ca68b) & 0xFFFFFFFF
+        v ^= v >> 16
+        return v
+    assert [hash32(v) for v in (0, 1, 2, 12345, 0xFFFFFFFF, 3840 * 2160 - 1)] == [0, 1753845952, 3507691905, 2435775735, 1734902346, 3873009951]
+    from raytracedshadows_amd import scenes, workloads
+    wl = workloads.prepare("cornell", 64, 48, spp=16, via_obj=False)
+    k = wl.constants.as_array()
+    lt = oracle.light_from_product(wl.light, wl.constants)
+    base, _, _ = oracle.shadow_mask(wl.packed, k, lt, wl.positions, 64, 48)
+    lt.table = 16
+    rot, _, _ = oracle.shadow_mask(wl.packed, k, lt, wl.positions, 64, 48)
+    assert (rot == base).all()
+    # the rays themselves: pixel p, sample j aims at offsets[(start(p) + j) % T]
+    rays_plain = oracle.gen_rays(k, oracle.light_from_product(wl.light, wl.constants), wl.positions).reshape(-1, 16, 8)
+    rays_rot = oracle.gen_rays(k, lt, wl.positions).reshape(-1, 16, 8)
+    for p in (0, 1, 77, 64 * 48 - 1):
+        start = (hash32(p) * 16) >> 32
+        for j in (0, 5, 15):
+            assert (rays_rot[p, j] == rays_plain[p, (start + j) % 16]).all()
+    big = workloads.relight(wl, "point", 16, table=64)
+    lt64 = oracle.light_from_product(big.light, big.constants)
+    assert lt64.table == 64 and lt64.nsamples == 16
+    other, _, _ = oracle.shadow_mask(wl.packed, k, lt64, wl.positions, 64, 48)
+    assert (other != base).any() and other.max() == 16
