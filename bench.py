@@ -57,7 +57,10 @@ BAND = 32
 
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"],
+              ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"],
               ["TCC_HIT_sum", "TCC_MISS_sum"]]
+PMC_PASSES_SECONDARY = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]]
+SECONDARY = {"city_4k": ["courtyard_4k", "atrium_1080p", "city_4k_soft16"]}     # driver-run lines besides the headline
 
 
 def log(*a):
@@ -67,7 +70,7 @@ def log(*a):
 def source_hash():
     """Identifies the kernel build a set of counters belongs to."""
     h = hashlib.sha256()
-    for rel in ("rts_kernels.hip", "rts_packet_asm.inc", "rts_device.h", "Makefile"):
+    for rel in ("rts_kernels.hip", "rts_packet_asm.inc", "rts_wide_asm.inc", "rts_wide.hip", "rts_device.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "raytracedshadows_amd", "csrc", rel), "rb").read())
     return h.hexdigest()[:16]
 
@@ -91,15 +94,18 @@ def _per_dispatch(csv_dir, kernel_substr="shadowMask"):
     return out
 
 
-def live_counters(args, say):
+def live_counters(args, say, config=None, kernel=None, passes=None, trace=True):
     """Runs `bench.py --pmc-child` under rocprofv3 once per counter group; returns a dict or None."""
+    config = config or args.config
+    kernel = args.kernel if kernel is None else kernel
+    passes = passes or PMC_PASSES
     prof = shutil.which("rocprofv3")
     if not prof:
         say("rocprofv3 not found: no live counters")
         return None
     work = tempfile.mkdtemp(prefix="rts_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--kernel", str(args.kernel),
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--kernel", str(kernel),
              "--prewarm-seconds", "0"]
     res = {"source": "live: rocprofv3 --pmc child passes of this command in this run", "passes": []}
     t_all = time.time()
@@ -131,7 +137,7 @@ def live_counters(args, say):
                                "workgroup": int(row.get("Workgroup_Size_X", 0) or 0),
                                "vgpr": int(row.get("VGPR_Count", 0) or 0), "sgpr": int(row.get("SGPR_Count", 0) or 0)}
         counters, calib = {}, {}
-        for i, group in enumerate(PMC_PASSES):
+        for i, group in enumerate(passes):
             d = os.path.join(work, f"pmc{i}")
             r = subprocess.run([prof, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
                                env=env, capture_output=True, text=True, timeout=240)
@@ -204,6 +210,10 @@ def roofline_bounds(counters, avg_launch_s, clock_mhz):
                     issue[k.lower()] = int(c[k])
             if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
                 issue["wait_any_share_of_wave_cycles"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+            if c.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in c:
+                # lanes enabled in EXEC per VALU instruction; the packet loops keep EXEC wide and mask in SGPRs, so this is
+                # an upper bound of the useful share -- the algorithmic one is `lane_fill_members` (oracle)
+                issue["lane_fill_exec"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 3)
         roof["counters_source"] = counters.get("source")
         roof["source_hash"] = source_hash()
         if "kernel_trace" in counters:
@@ -259,25 +269,154 @@ def pmc_child(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def packet_model(oracle, wl, kname):
+    """What the packet walk of this kernel family does on this frame, counted by the oracle (first light sample):
+    `lane_fill_members` = rays that take part in a box test / 64 per wave-wide test, and the packet-granular byte model
+    (a node is fetched once per WAVE: 32 B per node of a tile's union + 16 B per leaf's v0 for the stackless packet,
+    128 B per wide node + 64 B per triangle record for the wide one; + 17 B per pixel for the texel and the mask byte)."""
+    import ctypes as C
+    o = oracle._o
+    W, H = wl.W, wl.H
+    k = np.ascontiguousarray(wl.constants.as_array(), np.float32)
+    lt = oracle.light_from_product(wl.light, wl.constants)
+    packed = np.ascontiguousarray(wl.packed, np.uint32)
+    pos = np.ascontiguousarray(wl.positions, np.float32)
+    spp = max(1, wl.spp)
+    if "wide" in kname:
+        o.orc_wide_packet_sim.restype = None
+        o.orc_wide_packet_sim.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
+                                          C.c_void_p, C.c_void_p]
+        out = np.zeros(16, np.uint64)
+        o.orc_wide_packet_sim(oracle._p(packed), oracle._p(k), C.byref(lt), oracle._p(pos), W, H, 12, 16, oracle._p(out), None)
+        steps, box_t, box_lanes, tri_t = int(out[1]), int(out[2]), int(out[3]), int(out[4])
+        return {"model": "wide packet: 128 B per wide node a tile enters + 64 B per triangle record + 17 B per pixel",
+                "nodes_per_tile": round(steps / max(1, int(out[0])), 2), "lane_fill_members": round(box_lanes / max(1, 64 * box_t), 3),
+                "bytes_per_launch": int((128 * steps + 64 * tri_t + 17 * W * H) * spp)}
+    o.orc_tile_union_stats.restype = None
+    o.orc_tile_union_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    out = np.zeros(8, np.uint64)
+    o.orc_tile_union_stats(oracle._p(packed), oracle._p(k), C.byref(lt), oracle._p(pos), W, H, oracle._p(out))
+    U, V, leaf_u = int(out[1]), int(out[3]), int(out[4])
+    return {"model": "stackless packet: 32 B per node of a tile's union + 16 B per leaf (v0) + 17 B per pixel",
+            "nodes_per_tile": round(U / max(1, int(out[0])), 2), "lane_fill_members": round(V / max(1, 64 * U), 3),
+            "bytes_per_launch": int((32 * U + 16 * leaf_u + 17 * W * H) * spp)}
+
+
+def tune_child(args):
+    """`bench.py --tune-child`: which kernel rts_ctx_autotune picks for this workload (its own process, before any profiler pass)."""
+    from raytracedshadows_amd import api, workloads
+    wl = workloads.prepare_config(args.config, cache=True)
+    with api.ShadowContext(0) as ctx:
+        ctx.set_bvh(wl.packed)
+        d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(wl.W * wl.H)
+        ctx.h2d(d_pos, wl.positions)
+        for _ in range(100):                                    # ramp the clocks first: the candidates must meet equal conditions
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
+        ctx.synchronize()
+        chosen, ms = ctx.autotune(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+    print(json.dumps({"kernel": chosen, "ms": ms}))
+
+
+def pick_kernel(args, config, say):
+    """Kernel id for `config`: the caller's --kernel, else the autotuner's choice (a child process: this one must not touch the
+    GPU before the profiler passes have run)."""
+    if args.kernel >= 0:
+        return args.kernel
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tune-child", "--config", config], cwd="/tmp",
+                           capture_output=True, text=True, timeout=300)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        say(f"autotune [{config}]: kernel {rec['kernel']} ({rec['ms']:.4f} ms)")
+        return int(rec["kernel"])
+    except Exception as e:
+        say(f"autotune child failed for {config} ({e!r}): library default")
+        return -1
+
+
+def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=0):
+    """The timed region of the contract: time-based pre-warm, W untimed steps, exactly K steps between synchronisations."""
+    t0 = time.perf_counter()
+    prewarm_launches = 0
+    while time.perf_counter() - t0 < prewarm_seconds:
+        for _ in range(50):
+            step()
+        ctx.synchronize()
+        prewarm_launches += 50
+    for _ in range(warmup):
+        step()
+    if probe_rows:
+        ctx.set_option("clock_probe", probe_rows)                # the timed launches stamp their own clock
+    if barrier:
+        barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ctx.timer_mark(i)
+        step()
+    ctx.timer_mark(steps)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    if barrier:
+        barrier()
+    per_launch = np.array([ctx.timer_between_ms(i, i + 1) for i in range(steps)])   # HIP events, launch stream
+    clock = None
+    if probe_rows:
+        try:
+            clock = ctx.clock_probe_mhz(probe_rows)
+        finally:
+            ctx.set_option("clock_probe", 0)
+    return {"wall": wall, "kernel_ms": float(per_launch.sum()), "median_ms": float(np.median(per_launch)),
+            "prewarm_launches": prewarm_launches, "clock_mhz": clock}
+
+
+def parity_gate(ctx, oracle, wl, rows, step, d_mask, threads, who):
+    """GPU mask == CPU oracle mask on every pixel of `rows`; returns (visits, leaf tests, the mask)."""
+    W, H = wl.W, wl.H
+    olight = oracle.light_from_product(wl.light, wl.constants)
+    want = np.zeros((H, W), np.uint8)
+    V = L = 0
+    for b, e in rows:
+        _, v, l = oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, wl.positions, W, H, b, e, threads=threads, out=want)
+        V += v
+        L += l
+    step()
+    ctx.synchronize()
+    got = np.zeros((H, W), np.uint8)
+    ctx.d2h(got, d_mask)
+    own = np.zeros(H, bool)
+    for b, e in rows:
+        own[b:e] = True
+    bad = int((got[own] != want[own]).sum())
+    if bad:
+        raise SystemExit(f"{who}: GPU mask differs from the CPU oracle on {bad} pixels -- not timing")
+    return V, L, got
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="city_4k")
-    ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = library default)")
+    ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = what rts_ctx_autotune picks for the frame)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline workload (no config.secondary)")
     ap.add_argument("--no-probes", action="store_true",
                     help="skip the dispatch-floor and shader-clock probes (profiler runs: only the timed kernel is launched)")
     ap.add_argument("--save-counters", default="", help="write the live counter passes to this JSON file (the committed fallback "
                                                           "profiles/**/counters_<config>.json that is used when rocprofv3 is not available)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--tune-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.tune_child:
+        return tune_child(args)
 
     # stdout carries exactly ONE JSON line (rank 0): everything else any library prints to fd 1 (gloo announces
     # its connections there) goes to stderr
@@ -328,29 +467,52 @@ def main():
         shared_packed = buf.numpy().view(np.uint32)
     if dist:
         wl = workloads.prepare(scene, W, H, light=light_kind, spp=spp, threads=host_threads, log=say,
-                               via_obj=False, packed=shared_packed, radius=workloads.SOFT_RADIUS.get(args.config, 0.01))
+                               via_obj=False, packed=shared_packed, radius=workloads.SOFT_RADIUS.get(args.config, 0.01),
+                               table=workloads.PER_PIXEL_TABLE.get(args.config, 0))
     else:
         wl = workloads.prepare_config(args.config, cache=True, threads=host_threads, log=say)
     rays_per_frame = wl.rays
 
-    # ---- counters of this command, collected by child processes while this one has not touched the GPU yet ----
+    # ---- kernel choice and counters, by child processes while this one has not touched the GPU yet ----------------
+    secondary_names = [] if (N > 1 or args.no_secondary) else SECONDARY.get(args.config, [])
+    kernel_id = pick_kernel(args, args.config, say) if N == 1 else args.kernel
     counters = None
     if N == 1 and not args.no_pmc:
-        counters = live_counters(args, say)
+        counters = live_counters(args, say, kernel=kernel_id)
+    secondary_plan = []
+    for name in secondary_names:
+        kid = pick_kernel(args, name, say)
+        cnt = None if args.no_pmc else live_counters(args, say, config=name, kernel=kid, passes=PMC_PASSES_SECONDARY)
+        secondary_plan.append((name, kid, cnt))
 
     my_rows = partition.stripe_rows(H, N, rank, band=BAND, interleaved=True) if striped else [(0, H)]
     my_rays = sum(e - b for b, e in my_rows) * W * max(1, spp)
 
-    # RTS_BENCH_SINGLE_DEVICE=1: rehearsal of the multi-rank flow on a one-GPU box (all ranks share device 0)
-    device = 0 if os.environ.get("RTS_BENCH_SINGLE_DEVICE") else local_rank
+    # One process per GPU.  RTS_BENCH_SINGLE_DEVICE=1: rehearsal of the multi-rank flow on a one-GPU box (all ranks share
+    # device 0); otherwise two ranks on one device would silently halve the result, so that is refused.
+    single = bool(os.environ.get("RTS_BENCH_SINGLE_DEVICE"))
+    device = 0 if single else local_rank
+    if dist:
+        import torch
+        mine = torch.tensor([device, api.device_count()], dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(N)]
+        dist.all_gather(seen, mine)
+        ordinals = [int(t[0]) for t in seen]
+        if not single and (len(set(ordinals)) != N or device >= api.device_count()):
+            raise SystemExit(f"rank {rank}: device ordinals {ordinals} on a node with {api.device_count()} visible GPUs: one process "
+                             "per GPU is required (set RTS_BENCH_SINGLE_DEVICE=1 to rehearse the flow on one device)")
+    else:
+        ordinals = [device]
     ctx = api.ShadowContext(device)
     ctx.set_bvh(wl.packed)
-    if args.kernel >= 0:
-        ctx.set_option("kernel", args.kernel)
     d_pos = ctx.malloc(wl.positions.nbytes)
     d_mask = ctx.malloc(W * H)
     ctx.h2d(d_pos, wl.positions)
     ctx.h2d(d_mask, np.zeros((H, W), np.uint8))
+    if N > 1 and args.kernel < 0:                               # every rank tunes on its own device (the full frame, untimed)
+        kernel_id, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+    if kernel_id >= 0:
+        ctx.set_option("kernel", kernel_id)
 
     def one_step(c=ctx):                  # ONE dispatch per step on every rank
         if striped:
@@ -361,65 +523,17 @@ def main():
     # ---- correctness gate: GPU mask == CPU oracle mask, every pixel this rank owns -----------------
     import oracle  # the checker; never on the measured path
     olight = oracle.light_from_product(wl.light, wl.constants)
-    want = np.zeros((H, W), np.uint8)
-    V = L = 0
-    for b, e in my_rows:
-        _, v, l = oracle.shadow_mask(wl.packed, wl.constants.as_array(), olight, wl.positions, W, H, b, e,
-                                     threads=host_threads, out=want)
-        V += v
-        L += l
-    one_step()
-    ctx.synchronize()
-    got = np.zeros((H, W), np.uint8)
-    ctx.d2h(got, d_mask)
-    own = np.zeros(H, bool)
-    for b, e in my_rows:
-        own[b:e] = True
-    mismatches = int((got[own] != want[own]).sum())
-    if mismatches:
-        raise SystemExit(f"rank {rank}: GPU mask differs from the CPU oracle on {mismatches} pixels -- not timing")
+    V, L, got = parity_gate(ctx, oracle, wl, my_rows, one_step, d_mask, host_threads, f"rank {rank}")
     say(f"parity gate: {my_rays} rays bit-exact vs oracle (V/ray {V / my_rays:.2f}, L/ray {L / my_rays:.2f})")
     alg_bytes_per_step = 32 * V + 16 * L + 17 * (my_rays // max(1, spp))
     kname = ctx.last_kernel_name()
 
-    # ---- pre-warm: back-to-back launches until the clocks have ramped (the parity gate left the GPU idle for seconds;
-    #      five warm-up frames are 1 ms of work) -------------------------------------------------------------------
-    t0 = time.perf_counter()
-    prewarm_launches = 0
-    while time.perf_counter() - t0 < args.prewarm_seconds:
-        for _ in range(50):
-            one_step()
-        ctx.synchronize()
-        prewarm_launches += 50
-
-    # ---- timed region -------------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        one_step()
-    if dist:
-        dist.barrier()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ctx.timer_mark(i)
-        one_step()
-    ctx.timer_mark(args.steps)
-    ctx.synchronize()
-    wall = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-    per_launch = np.array([ctx.timer_between_ms(i, i + 1) for i in range(args.steps)])   # HIP events, launch stream
-    kernel_ms = float(per_launch.sum())
-    median_ms = float(np.median(per_launch))
-
-    # ---- shader clock held under this load (diagnostics build of the same kernel, after the timed region) --------
-    clock_mhz = None
-    if kname.startswith("shadowMaskPacketKernel") and not striped and not args.no_probes:
-        try:
-            for _ in range(50):
-                one_step()
-            clock_mhz = ctx.measure_shader_clock_mhz(one_step, ((W + 7) // 8) * ((H + 7) // 8), launches=20)
-        except Exception as e:
-            say(f"clock measurement failed: {e!r}")
+    # ---- timed region (pre-warm, W warm-up steps, exactly K steps between barrier + synchronize) --------------------
+    packet_kernel = kname.startswith("shadowMaskPacketKernel")
+    probe_rows = ((H + 7) // 8) if (packet_kernel and not striped and not args.no_probes) else 0
+    m = measure(ctx, one_step, args.steps, args.warmup, args.prewarm_seconds, barrier=dist.barrier if dist else None,
+                probe_rows=probe_rows)
+    wall, kernel_ms, median_ms, clock_mhz, prewarm_launches = m["wall"], m["kernel_ms"], m["median_ms"], m["clock_mhz"], m["prewarm_launches"]
 
     # ---- the same dispatch against a one-triangle BVH: what the frame costs before any traversal ----------------
     floor_ms = float("nan")
@@ -427,8 +541,8 @@ def main():
         tri = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
         floor_ctx = api.ShadowContext(device)
         floor_ctx.set_bvh(api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes)
-        if args.kernel >= 0:
-            floor_ctx.set_option("kernel", args.kernel)
+        if kernel_id >= 0:
+            floor_ctx.set_option("kernel", kernel_id)
         for _ in range(20):
             one_step(floor_ctx)
         fl = []
@@ -465,14 +579,16 @@ def main():
                                f"{W}x{H}, 1 {light_kind} light, {max(1, spp)} spp, "
                                + ("one frame per GPU" if frames_per_step > 1 else
                                   f"one frame row-striped over {N} GPUs in interleaved {BAND}-row bands" if striped else "one frame"),
-                   "rays_per_frame": rays_per_frame, "kernel": kname, "bvh_bytes": int(wl.packed.nbytes),
+                   "rays_per_frame": rays_per_frame, "kernel": kname,
+                   "kernel_choice": "--kernel" if args.kernel >= 0 else "rts_ctx_autotune on this frame (untimed set-up)",
+                   "bvh_bytes": int(wl.packed.nbytes),
                    "ms_per_frame_gpu_median": round(max(g[2] for g in per_rank), 4),
                    "ms_per_frame_gpu_mean": round(max(g[1] for g in per_rank) / args.steps, 4),
                    "dispatch_floor_ms": None if args.no_probes else round(max(g[3] for g in per_rank), 4),
-                   "prewarm_launches": prewarm_launches},
+                   "prewarm_launches": prewarm_launches, "device_ordinals": ordinals},
     }
     if N > 1:
-        result["config"]["per_rank"] = [{"rank": r, "wall_ms_per_step": round(g[0] / args.steps * 1e3, 4),
+        result["config"]["per_rank"] = [{"rank": r, "device": ordinals[r], "wall_ms_per_step": round(g[0] / args.steps * 1e3, 4),
                                          "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": None if args.no_probes else round(g[3], 4)}
                                         for r, g in enumerate(per_rank)]
 
@@ -481,8 +597,10 @@ def main():
             "algorithmic_GBps": round(alg_bytes_per_step / avg_launch_s / 1e9, 1),
             "avg_launch_ms": round(avg_launch_s * 1e3, 5), "median_launch_ms": round(median_ms, 5), "kernel": kname,
             "shader_clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+            "shader_clock_source": "stamps of the timed launches themselves (first wave of every tile row)" if clock_mhz else None,
             "note": "frac = the larger of two measured bounds (see the module docstring); algorithmic_* is SURVEY 8d's "
-                    "cache-oblivious 32V+16L+17 B/ray from the oracle's exact visit counts, informational"}
+                    "cache-oblivious 32V+16L+17 B/ray from the oracle's exact visit counts, informational; packet_bytes is the same "
+                    "model at the granularity this kernel fetches at (once per wave), a fraction of the HBM peak <= 1"}
     if counters and args.save_counters:
         rec = dict(counters, source_hash=source_hash(), workload=args.config, kernel=kname)
         with open(args.save_counters, "w") as fh:
@@ -490,6 +608,17 @@ def main():
     if N == 1 and counters is None and not args.no_pmc:
         counters = committed_counters(kname, args.config, say)
     roof.update(roofline_bounds(counters, avg_launch_s, clock_mhz))
+    if N == 1 and packet_kernel:
+        try:
+            pm = packet_model(oracle, wl, kname)
+            pm["achieved"] = round(pm["bytes_per_launch"] / avg_launch_s / 1e9, 1)
+            pm["peak"], pm["unit"] = HBM_PEAK_GBS, "GB/s"
+            pm["frac"] = round(pm["achieved"] / HBM_PEAK_GBS, 4)
+            roof["packet_bytes"] = pm
+            if roof.get("valu_issue"):
+                roof["valu_issue"]["lane_fill_members"] = pm["lane_fill_members"]
+        except Exception as e:
+            say(f"packet model failed: {e!r}")
     result["roofline"] = roof
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on the host cores, same frame ---------------
@@ -520,6 +649,60 @@ def main():
     ctx.free(d_pos)
     ctx.free(d_mask)
     ctx.close()
+
+    # ---- the other workloads (N = 1): the same protocol -- parity gate on every pixel, pre-warm, 20 timed steps -- no CPU
+    #      baseline; their counters come from their own profiler passes (above) --------------------------------------------
+    secondary = {}
+    for name, kid, cnt in secondary_plan:
+        try:
+            t_start = time.time()
+            swl = workloads.prepare_config(name, cache=True, threads=host_threads, log=say)
+            sW, sH = swl.W, swl.H
+            sctx = api.ShadowContext(device)
+            sctx.set_bvh(swl.packed)
+            if kid >= 0:
+                sctx.set_option("kernel", kid)
+            sd_pos, sd_mask = sctx.malloc(swl.positions.nbytes), sctx.malloc(sW * sH)
+            sctx.h2d(sd_pos, swl.positions)
+
+            def sstep():
+                sctx.trace_shadow_mask_device(swl.constants, sd_pos, sW, sH, sd_mask, light=swl.light)
+
+            sV, sL, _ = parity_gate(sctx, oracle, swl, [(0, sH)], sstep, sd_mask, host_threads, name)
+            sk = sctx.last_kernel_name()
+            spacket = sk.startswith("shadowMaskPacketKernel")
+            sm = measure(sctx, sstep, 20, 5, args.prewarm_seconds, probe_rows=((sH + 7) // 8) if spacket else 0)
+            s_avg = sm["kernel_ms"] / 1e3 / 20
+            rec = {"workload": f"{name}: {workloads.CONFIGS[name][0]} ({swl.prim_count} triangles), {sW}x{sH}, {max(1, swl.spp)} spp",
+                   "kernel": sk, "parity": f"{swl.rays} rays bit-exact vs the oracle", "steps": 20, "warmup": 5,
+                   "value": round(swl.rays * 20 / sm["wall"] / 1e6, 1), "unit": "Mrays/s",
+                   "ms_per_frame_gpu_median": round(sm["median_ms"], 4),
+                   "nodes_per_ray": round(sV / swl.rays, 2), "triangle_tests_per_ray": round(sL / swl.rays, 2),
+                   "shader_clock_mhz": round(sm["clock_mhz"], 1) if sm["clock_mhz"] else None}
+            sroof = roofline_bounds(cnt, s_avg, sm["clock_mhz"]) if cnt else None
+            if sroof:
+                rec["bound"], rec["frac"] = sroof["bound"], sroof["frac"]
+                rec["valu_issue"] = sroof.get("valu_issue")
+                rec["hbm"] = {k: sroof["hbm"][k] for k in ("frac", "achieved", "bytes_per_launch")} if sroof.get("hbm") else None
+            if spacket:
+                pm = packet_model(oracle, swl, sk)
+                pm["frac"] = round(pm["bytes_per_launch"] / s_avg / 1e9 / HBM_PEAK_GBS, 4)
+                rec["packet_bytes"] = pm
+                if rec.get("valu_issue"):
+                    rec["valu_issue"]["lane_fill_members"] = pm["lane_fill_members"]
+            rec["seconds"] = round(time.time() - t_start, 1)
+            secondary[name] = rec
+            say(f"secondary [{name}]: {rec['value']} Mrays/s, {rec['ms_per_frame_gpu_median']} ms ({sk})")
+            sctx.free(sd_pos)
+            sctx.free(sd_mask)
+            sctx.close()
+        except SystemExit:
+            raise
+        except Exception as e:                                    # a secondary workload must never cost the headline line
+            secondary[name] = {"error": repr(e)}
+    if secondary:
+        result["config"]["secondary"] = secondary
+
     if dist:
         dist.barrier()
         dist.destroy_process_group()

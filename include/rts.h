@@ -228,6 +228,16 @@ int rts_device_mem_info(rts_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
  * those iterations (0-31)};
  * this copies them out. */
 int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
+/* After rts_ctx_set_option(ctx, "clock_probe", tile_rows) every launch of a packet kernel on a 2-D grid -- the everyday
+ * instantiation included, so the launches that are TIMED -- stamps, for the first wave of each tile row, {shader clock at
+ * start, at end, 100 MHz clock at start, at end} (4 x u64 per row): clock held = sum(d shader) / sum(d 100 MHz) * 100 MHz. */
+int rts_ctx_read_clock_probe(rts_ctx* ctx, uint64_t* out, size_t rows);
+/* Picks the kernel for this frame by timing the candidates on it (lane-per-ray with work sharing for small frames, the
+ * packet kernel, the wide packet kernel) -- what a renderer does once per scene and resolution; leaves option "kernel" set
+ * to the winner (*chosen, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
+ * Results never depend on the choice. */
+int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                     uint32_t W, uint32_t H, uint8_t* d_mask, int* chosen, float* ms);
 /* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks
  * from the wave's start to its first ray being ready (G-buffer texel in, ray set up), XCC id.  With the start/end shader
  * clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */

@@ -146,6 +146,9 @@ _sig("rts_ctx_last_kernel_name", C.c_char_p, C.c_void_p)
 _sig("rts_ctx_set_tile_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_realtime", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_ctx_read_clock_probe", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+     C.POINTER(C.c_int), C.POINTER(C.c_float))
 _sig("rts_timer_mark", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
 _sig("rts_timer_between_ms", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 _sig("rts_device_mem_info", C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
@@ -394,6 +397,23 @@ class ShadowContext:
         out = np.zeros((waves, 4), dtype=np.uint64)
         _check(_lib.rts_ctx_read_wave_realtime(self._h, _ptr(out), waves), "rts_ctx_read_wave_realtime")
         return out
+
+    def autotune(self, constants, d_positions, width, height, d_mask, light=None):
+        """rts_ctx_autotune: times the candidate kernels on this frame, keeps the fastest; returns (kernel id, ms)."""
+        chosen, ms = C.c_int(-1), C.c_float(0)
+        lp = C.byref(light) if light is not None else None
+        _check(_lib.rts_ctx_autotune(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
+                                     C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)), "rts_ctx_autotune")
+        return int(chosen.value), float(ms.value)
+
+    def clock_probe_mhz(self, rows):
+        """Shader clock held during the launches since set_option("clock_probe", rows) (the timed launches themselves)."""
+        out = np.zeros((rows, 4), np.uint64)
+        _check(_lib.rts_ctx_read_clock_probe(self._h, _ptr(out), rows), "rts_ctx_read_clock_probe")
+        ok = (out[:, 1] > out[:, 0]) & (out[:, 3] > out[:, 2])
+        if not ok.any():
+            return None
+        return float((out[ok, 1] - out[ok, 0]).astype(np.float64).sum() / (out[ok, 3] - out[ok, 2]).astype(np.float64).sum() * 100.0)
 
     def measure_shader_clock_mhz(self, trace, waves, launches=8):
         """Clock the chip holds while `trace()` (one dispatch of a packet kernel with `waves` one-wave workgroups) runs

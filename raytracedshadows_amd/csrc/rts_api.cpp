@@ -47,6 +47,7 @@ struct rts_ctx {
     int wideLane = 1;                        // option "wide_lane": dissolved wide packets walk the wide nodes lane per ray
     int softSplit = 1;                       // option "soft_split": soft shadows with 4 waves per tile (samples side by side)
     uint32_t pixelBase = 0;                  // set around a host-pointer stripe (see rts_trace_shadow_mask)
+    uint64_t* d_clockProbe = nullptr; size_t clockProbeRows = 0;    // option "clock_probe"
 };
 
 namespace {
@@ -214,6 +215,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_word) (void)hipFree(c->d_word);
+    if (c->d_clockProbe) (void)hipFree(c->d_clockProbe);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -251,6 +253,16 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "wide_copy")) { c->wideCopy = value ? 1 : 0; return RTS_OK; }      // takes effect at the next upload / build
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "clock_probe")) {          // value = tile rows to stamp (0 = off); packet kernels on 2-D grids
+        RTS_HIP(hipSetDevice(c->device));
+        if (c->d_clockProbe) { RTS_HIP(hipFree(c->d_clockProbe)); c->d_clockProbe = nullptr; c->clockProbeRows = 0; }
+        if (value > 0) {
+            RTS_HIP(hipMalloc((void**)&c->d_clockProbe, (size_t)value * 32));
+            RTS_HIP(hipMemset(c->d_clockProbe, 0, (size_t)value * 32));
+            c->clockProbeRows = (size_t)value;
+        }
+        return RTS_OK;
+    }
     if (!strcmp(key, "wave_stats")) {            // diagnostics: value = number of waves to record (0 = off)
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_waveStats) { RTS_HIP(hipFree(c->d_waveStats)); c->d_waveStats = nullptr; c->waveStatsBytes = 0; }
@@ -332,6 +344,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
+    if (c->d_clockProbe && p.grid2d && p.blocksY <= c->clockProbeRows) p.clockProbe = c->d_clockProbe;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
     for (int i = 0; i < 3; ++i) p.cam[i] = k->cameraPosition[i];
     if (light) {
@@ -560,6 +573,48 @@ int rts_ctx_read_wave_stats(rts_ctx* c, uint64_t* out, size_t waves) {
     if (!c || !out || !c->d_waveStats || waves * 32 > c->waveStatsBytes) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
     RTS_HIP(hipMemcpy(out, c->d_waveStats, waves * 32, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+int rts_ctx_read_clock_probe(rts_ctx* c, uint64_t* out, size_t rows) {
+    if (!c || !out || !c->d_clockProbe || rows > c->clockProbeRows) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipMemcpy(out, c->d_clockProbe, rows * 32, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+// Picks the kernel for THIS frame by timing the candidates on it (what a renderer does once per scene and resolution):
+// the lane-per-ray walk with work sharing, the packet kernel, the wide packet kernel (when the stream has a private copy).
+// Leaves option "kernel" set to the winner.  Results never depend on the choice.
+int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W,
+                     uint32_t H, uint8_t* d_mask, int* chosen, float* ms_out) {
+    if (!c || !k || !d_positions || !d_mask) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    const int candidates[3] = { rts::V_PACKET, rts::V_WIDE, rts::V_SHARE };
+    const int before = c->variant;
+    int best = before;
+    float bestMs = 1e30f;
+    for (int v : candidates) {
+        if (v == rts::V_WIDE && !c->wideCount) continue;
+        if (v == rts::V_SHARE && (uint64_t)W * H > (1u << 20)) continue;        // (never close on a big frame: skip its long launches)
+        c->variant = v;
+        float times[5];
+        for (int i = -2; i < 5; ++i) {
+            RTS_HIP(hipEventRecord(c->ev0, nullptr));
+            int s = rts_trace_shadow_mask_device(c, k, light, d_positions, W, H, 0, H, d_mask, nullptr);
+            if (s != RTS_OK) { c->variant = before; return s; }
+            RTS_HIP(hipEventRecord(c->ev1, nullptr));
+            RTS_HIP(hipEventSynchronize(c->ev1));
+            float ms = 0;
+            RTS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            if (i >= 0) times[i] = ms;
+        }
+        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
+        if (times[2] < bestMs) { bestMs = times[2]; best = v; }
+    }
+    c->variant = best;
+    if (chosen) *chosen = best;
+    if (ms_out) *ms_out = bestMs;
     return RTS_OK;
 }
 

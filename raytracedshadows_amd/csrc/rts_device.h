@@ -48,6 +48,8 @@ struct TraceParams {
     const uint32_t* tileOrder; // optional: block i works on tile tileOrder[i] (device array of nBlocks entries)
     uint64_t* waveStats;      // diagnostics (tools/wave_stats.py): 4 u64 per wave, or NULL
     uint64_t* waveRealtime;   // diagnostics: 4 u64 per wave {s_memrealtime at start, at end (100 MHz), clocks to first ray, XCC id}
+    uint64_t* clockProbe;     // diagnostics that the EVERYDAY instantiation carries too: the first wave of every tile row
+                              // stamps {shader clock, 100 MHz clock} at its start and end (4 u64 per row), or NULL
     uint32_t packetBudget;    // side-steps between two coherence checks of a packet (dissolve rule)
     uint32_t packetShare;     // dissolve when rays served per step < packetShare/16 of the rays alive
     const void* wide;         // private wide nodes (128 B each, root first) or NULL: V_WIDE falls back to V_PACKET

@@ -1054,6 +1054,12 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
     const NodeStream bvh = openStream(p);
     const uint32_t ns = SOFT ? p.nsamples : 1u;
+    // clock probe (every instantiation, so that the clock is measured on the launches that are timed): one wave per tile row
+    // (the stamps go straight to memory: nothing of the probe stays in registers across the walk)
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t* o = p.clockProbe + (size_t)(p.grid2d ? blockIdx.y : 0u) * 4;
+        o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
+    }
     const uint64_t tStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
     const uint64_t rStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memrealtime() : 0;
     int32_t left = 0;
@@ -1092,6 +1098,10 @@ void shadowMaskPacketKernel(TraceParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
+    }
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t* o = p.clockProbe + (size_t)(p.grid2d ? blockIdx.y : 0u) * 4;
+        o[1] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
     }
     if (!PLAIN && p.waveStats && lane == 0) {    // diagnostics: never read by any kernel, never part of an output
         const size_t slot = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WPB * SPLIT) + wave;

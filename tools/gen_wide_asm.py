@@ -25,6 +25,7 @@ import sys
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    "raytracedshadows_amd", "csrc", "rts_wide_asm.inc")
 BASE = 20
+PREFETCH = False    # pushed nodes requested at push time: measured, no effect
 AX = "xyz"
 
 
@@ -251,8 +252,13 @@ def loop(octant):
               f"v_writelane_b32 %[vref], {N(24 + k)}, m0",
               f"v_writelane_b32 %[vlo], {s(48 + 2 * k)}, m0",
               f"v_writelane_b32 %[vhi], {s(49 + 2 * k)}, m0",
-              "s_add_u32 %[sp], %[sp], 1",
-              f"s_branch 2{k}b"]
+              "s_add_u32 %[sp], %[sp], 1"]
+        if PREFETCH:
+            # the node will be popped later: ask for its two cache lines now (into two registers nobody reads; every
+            # later s_waitcnt lgkmcnt(0) covers them), so that the pop finds them in the scalar cache
+            L += [f"s_load_dword {s(66)}, %[wb], {N(24 + k)}",
+                  f"s_load_dword {s(67)}, %[wb], {N(24 + k)} offset:64"]
+        L += [f"s_branch 2{k}b"]
     # ---- out of line: leaf slot k ------------------------------------------------------------------------------------
     for k in range(4):
         L += [f"3{k}:",
@@ -290,7 +296,7 @@ def emit(octant, ind):
     ins += [f'[o{a}] "v"(r.o.{a})' for a in AX] + [f'[i{a}] "v"(r.inv.{a})' for a in AX] + [f'[d{a}] "v"(r.d.{a})' for a in AX]
     ins += ['[tm] "v"(r.tmax)']
     ins += [f'[cu{a}] "v"(w.cU.{a})' for a in AX] + [f'[cd{a}] "v"(w.cD.{a})' for a in AX]
-    clob = [f'"s{i}"' for i in range(BASE, BASE + 66)] + ['"vcc"', '"scc"', '"m0"']
+    clob = [f'"s{i}"' for i in range(BASE, BASE + (68 if PREFETCH else 66))] + ['"vcc"', '"scc"', '"m0"']
     return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
             f"{ind}    : {', '.join(clob)});\n")
 
