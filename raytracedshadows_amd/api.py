@@ -234,15 +234,30 @@ def bvh_build_device(ctx, vertices, stride, indices, prim_count, install=False, 
     "ploc_sah" (PLOC below 65 536 clusters, full-sweep SAH over the clusters on the host above).
     ``vertices`` may be ``(device pointer, number of floats)`` and ``indices`` a device pointer: geometry that already lives on
     the context's device is used in place.  Returns (packed or None, device milliseconds)."""
+    import numbers
+
+    def device_pointer(v):                           # a plain or numpy integer, or a ctypes pointer value
+        if isinstance(v, C.c_void_p):
+            v = v.value
+        if isinstance(v, numbers.Integral) and not isinstance(v, bool) and int(v) > 0:
+            return int(v)
+        return None
+
     if isinstance(vertices, tuple):                  # (device pointer, number of floats): geometry already on the device
-        v_ptr, v_floats = C.c_void_p(vertices[0]), int(vertices[1])
+        if len(vertices) != 2 or device_pointer(vertices[0]) is None or int(vertices[1]) < 3 * stride:
+            raise ValueError("vertices: expected (device pointer, number of floats >= 3 * stride)")
+        v_ptr, v_floats = C.c_void_p(device_pointer(vertices[0])), int(vertices[1])
     else:
         vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+        if vertices.ndim == 0 or vertices.size < 3 * stride:
+            raise ValueError("vertices: an array of at least one triangle's floats is required")
         v_ptr, v_floats = _ptr(vertices), vertices.size
-    if isinstance(indices, int):
-        i_ptr = C.c_void_p(indices)
+    if device_pointer(indices) is not None:
+        i_ptr = C.c_void_p(device_pointer(indices))
     else:
         indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        if indices.ndim == 0 or indices.size < 3 * prim_count:       # C reads 3 * prim_count words from this array
+            raise ValueError(f"indices: {indices.size} entries for {prim_count} triangles")
         i_ptr = _ptr(indices)
     n = packed_count(prim_count)
     packed = np.zeros((max(n, 1), 4), dtype=np.uint32) if want_packed else None

@@ -251,6 +251,12 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "lds_pad")) { if (value < 0 || value > 65536) return RTS_ERR_INVALID_ARG; c->ldsPad = value; return RTS_OK; }
     if (!strcmp(key, "packet_share")) { if (value < 0 || value > 16) return RTS_ERR_INVALID_ARG; c->packetShare = value; return RTS_OK; }
     if (!strcmp(key, "wide_copy")) { c->wideCopy = value ? 1 : 0; return RTS_OK; }      // takes effect at the next upload / build
+    if (!strcmp(key, "builder_scratch")) {          // 0: release the working memory the GPU builders keep between builds
+        if (value != 0) return RTS_ERR_INVALID_ARG;
+        RTS_HIP(hipSetDevice(c->device));
+        if (c->d_scratch) { void* old = c->d_scratch; c->d_scratch = nullptr; c->scratchBytes = 0; RTS_HIP(hipFree(old)); }
+        return RTS_OK;
+    }
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "clock_probe")) {          // value = tile rows to stamp (0 = off); packet kernels on 2-D grids
@@ -289,6 +295,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "bvh_ordered")) { *value = c->bvhOrdered ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "bvh_enclosed")) { *value = c->bvhEnclosed ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "wide_copy")) { *value = c->wideCopy; return RTS_OK; }
+    if (!strcmp(key, "builder_scratch")) { *value = (int)(c->scratchBytes >> 20); return RTS_OK; }     // MiB held
     if (!strcmp(key, "wide_lane")) { *value = c->wideLane; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { *value = c->softSplit; return RTS_OK; }
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
@@ -313,6 +320,11 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     p.mask = d_mask;
     p.W = W; p.H = H; p.rowBegin = row_begin; p.rowEnd = row_end;
     p.bandRows = band_rows; p.nStripes = n_stripes; p.stripe = stripe;
+    p.bandShift = 0xFFFFFFFFu;
+    if (n_stripes > 1 && band_rows % 8 == 0) {
+        const uint32_t tiles = band_rows / 8;
+        if ((tiles & (tiles - 1)) == 0) { uint32_t sh = 0; while ((1u << sh) < tiles) ++sh; p.bandShift = sh; }
+    }
     // V_AUTO: a packet's steps are a dependent chain, so it needs several waves per SIMD to overlap them;
     // a launch with fewer than ~4 waves per SIMD is faster lane-per-ray (with in-wave work sharing: measured
     // 5-20 % ahead of the plain loop on every small frame).  (Bigger packets, V_PACKET2/4, were
@@ -518,14 +530,22 @@ const char* rts_ctx_last_kernel_name(rts_ctx* c) { return c ? c->lastKernel : ""
 int rts_ctx_device_ordinal(rts_ctx* c) { return c ? c->device : 0; }
 
 // used by the GPU builders (rts_lbvh.hip): one buffer the context keeps between builds (a rebuild per frame pays no
-// hipMalloc / hipFree: fifty of them cost more than the build).  NULL if it cannot be had; the caller then allocates.
+// hipMalloc / hipFree: fifty of them cost more than the build).  NULL if it cannot be had; the builders then allocate
+// every buffer on their own (DeviceArena::getOwn).
 void* rts_ctx_scratch(rts_ctx* c, size_t bytes) {
     if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
     if (bytes > c->scratchBytes) {
+        // grows by at least half (a scene that grows a little every frame must not pay a hipFree -- a device-wide
+        // synchronisation -- per frame); option "builder_scratch" = 0 gives the memory back
+        size_t want = bytes > c->scratchBytes + c->scratchBytes / 2 ? bytes : c->scratchBytes + c->scratchBytes / 2;
         if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratchBytes = 0; }
         void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        c->d_scratch = p; c->scratchBytes = bytes;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        c->d_scratch = p; c->scratchBytes = want;
     }
     return c->d_scratch;
 }

@@ -32,6 +32,7 @@ struct TraceParams {
     uint8_t* mask;            // W x H bytes (device)
     uint32_t W, H, rowBegin, rowEnd;
     uint32_t bandRows, nStripes, stripe;   // interleaved stripes (nStripes <= 1: plain rowBegin..rowEnd)
+    uint32_t bandShift;                    // log2(bandRows / 8) when that is a power of two, else 0xFFFFFFFF
     uint32_t blocksX, blocksY, nBlocks, gridBlocks, swizzle;
     uint32_t grid2d;            // 1: launched as a blocksX x blocksY grid in natural order (no swizzle, no order table)
     uint32_t rowOrder;          // dispatch order of the tile rows (speed only): 0 first to last, 1 last to first, 2 middle row outwards

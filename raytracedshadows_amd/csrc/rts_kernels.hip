@@ -1022,9 +1022,13 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // SPLIT (soft shadows, K = 1, WPB = 1): SPLIT waves per workgroup work on the SAME 8x8 tile, wave w walks samples w,
 // w + SPLIT, ...; the counts meet in LDS and wave 0 stores the byte.  A pixel's samples then run side by side instead of
 // one after the other: a wave lives 1/SPLIT as long (shorter tail, finer-grained stripes).
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1>
+// BANDS (with PLAIN): the everyday launch of ONE STRIPE of a frame cut into interleaved bands (multi-GPU):
+// a band is 2^bandShift tile rows, so the frame row of a tile row is two shifts and a multiply on the scalar unit
+// instead of the general prologue with its per-lane division.
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false>
 __global__ __launch_bounds__(64 * WPB * SPLIT) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
+    static_assert(!BANDS || (PLAIN && K == 1 && WPB == 1), "the band form exists for the one-tile everyday launch only");
     static_assert(SPLIT == 1 || (K == 1 && WPB == 1 && SOFT), "samples are split over waves in the one-tile soft-shadow form only");
     __shared__ uint32_t shareSlots[WPB * SPLIT][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
@@ -1043,7 +1047,11 @@ void shadowMaskPacketKernel(TraceParams p) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t x = x0 + (k & 1) * 8u;
-        const uint32_t y = PLAIN ? p.rowBegin + v0 + (k >> 1) * 8u : ownedRow(p, v0 + (k >> 1) * 8u);
+        uint32_t y;
+        if constexpr (BANDS) {
+            const uint32_t band = by >> p.bandShift, within = by - (band << p.bandShift);
+            y = (band * p.nStripes + p.stripe) * p.bandRows + within * 8u + (lane >> 3);
+        } else y = PLAIN ? p.rowBegin + v0 + (k >> 1) * 8u : ownedRow(p, v0 + (k >> 1) * 8u);
         live[k] = (x < p.W) && (y < p.rowEnd);
         pix[k] = (size_t)y * p.W + x;
         rel[k] = F3{ 0.f, 0.f, 0.f };
@@ -1195,6 +1203,8 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         dim3 b1(64);
         if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1, 4>), grid, dim3(256), 0, stream, p);
         else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
+        else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1>), grid, b1, ldsPad, stream, p);
         else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 1>), grid, b1, ldsPad, stream, p);
@@ -1212,6 +1222,8 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         case V_PACKET:
             if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 0, 4>), grid, dim3(256), 0, stream, p);
             else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
+            else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
             else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);

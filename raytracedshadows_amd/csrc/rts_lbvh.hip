@@ -910,13 +910,14 @@ int deviceOf(const void* p) {
 struct DeviceArena {            // working buffers: carved out of the context's scratch buffer; what does not fit (and what
     char* slab = nullptr;       // must outlive the build) is a hipMalloc of its own, freed whatever path leaves the function
     size_t slabBytes = 0, used = 0;
-    void* own[16]; int nOwn = 0;
+    std::vector<void*> own;     // (no fixed limit: without the context's slab every buffer of a build lands here)
     hipEvent_t ev[2] = { nullptr, nullptr };
     template <typename T> hipError_t getOwn(T** p, size_t bytes) {
-        if (nOwn == 16) return hipErrorOutOfMemory;
         void* v = nullptr;
         hipError_t e = hipMalloc(&v, bytes ? bytes : 16);
-        if (e == hipSuccess) { own[nOwn++] = v; *p = (T*)v; }
+        if (e != hipSuccess) return e;
+        try { own.push_back(v); } catch (...) { (void)hipFree(v); return hipErrorOutOfMemory; }
+        *p = (T*)v;
         return e;
     }
     template <typename T> hipError_t get(T** p, size_t bytes) {
@@ -925,8 +926,8 @@ struct DeviceArena {            // working buffers: carved out of the context's 
         return getOwn(p, bytes);
     }
     void release(void* keep = nullptr) {
-        for (int i = 0; i < nOwn; ++i) if (own[i] != keep) (void)hipFree(own[i]);
-        nOwn = 0;
+        for (void* v : own) if (v != keep) (void)hipFree(v);
+        own.clear();
         for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
 };
@@ -955,8 +956,9 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             if ((size_t)indices[i] * stride + 3 > vertex_floats) return RTS_ERR_INVALID_ARG;
 
     DeviceArena arena;
-    arena.slabBytes = vertex_floats * 4 + (size_t)P * 600 + ((size_t)4 << 20);     // every buffer of the largest path (SAH) + sort scratch
-    arena.slab = (char*)rts_ctx_scratch(ctx, arena.slabBytes);
+    // every buffer of the largest path (SAH) + sort scratch; geometry that is used where it lies needs no room
+    arena.slabBytes = (vertsOn >= 0 ? 0 : vertex_floats * 4) + (idxOn >= 0 ? 0 : (size_t)P * 12) + (size_t)P * 588 + ((size_t)4 << 20);
+    arena.slab = getenv("RTS_NO_BUILDER_SLAB") ? nullptr : (char*)rts_ctx_scratch(ctx, arena.slabBytes);   // (test hook: the no-slab path)
     if (!arena.slab) arena.slabBytes = 0;
     Lbvh b{};
     b.P = P; b.stride = stride;

@@ -275,3 +275,49 @@ def test_error_codes(ctx):
     with pytest.raises(api.RtsError) as e:
         api.bvh_build_device(ctx, v[:5], 3, idx, 4)                  # index beyond the vertex array
     assert e.value.status == 1
+
+
+def test_builders_without_the_contexts_working_memory(ctx, monkeypatch):
+    """when the context cannot lend its slab, every buffer of a build is an allocation of its own (about sixty for
+    the SAH builder).  Forced here (RTS_NO_BUILDER_SLAB); the streams must equal the ones built out of the slab."""
+    sc = scenes.terrain(48, seed=4)
+    verts, idx = sc.flat()
+    for algo in ("sah", "lbvh", "ploc"):
+        with_slab, _ = api.bvh_build_device(ctx, verts, 8, idx, sc.triangle_count, algorithm=algo)
+        monkeypatch.setenv("RTS_NO_BUILDER_SLAB", "1")
+        without, _ = api.bvh_build_device(ctx, verts, 8, idx, sc.triangle_count, algorithm=algo)
+        monkeypatch.delenv("RTS_NO_BUILDER_SLAB")
+        assert (with_slab == without).all(), algo
+    assert ctx.get_option("builder_scratch") > 0
+    ctx.set_option("builder_scratch", 0)                                  # the working memory can be given back
+    assert ctx.get_option("builder_scratch") == 0
+    again, _ = api.bvh_build_device(ctx, verts, 8, idx, sc.triangle_count)
+    assert (again == api.bvh_build_device(ctx, verts, 8, idx, sc.triangle_count)[0]).all()
+
+
+def test_installed_device_stream_is_checked_on_the_device(ctx):
+    """a stream built AND installed on the device goes through the same checks as an uploaded one (one kernel over
+    all nodes: layout, finiteness, box order, enclosure).  Finite vertices whose edge v1 - v0 overflows: the stream is not
+    finite, the kernels must take the exact forms -- and do (mask == oracle on that very stream)."""
+    big = np.float32(3.0e38)
+    verts = np.array([[-big, 0, 0], [big, 0, 0], [0, 1, 0],                # e0 = v1 - v0 = +inf
+                      [0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    idx = np.arange(6, dtype=np.uint32)
+    packed, _ = api.bvh_build_device(ctx, verts, 3, idx, 2, install=True, algorithm="lbvh")
+    assert not np.isfinite(packed.view(np.float32)[:6, :3]).all()
+    assert ctx.get_option("bvh_finite") == 0 and ctx.get_option("wide_nodes") == 0
+    rs = np.random.RandomState(5)
+    rays = np.zeros((4096, 8), np.float32)
+    rays[:, :3] = rs.random_sample((4096, 3)) * 4 - 2
+    rays[:, 3] = 1e9
+    rays[:, 4:7] = rs.random_sample((4096, 3)) * 2 - 1
+    want, _, _ = oracle.trace_rays(packed, rays)
+    for k in range(ctx.get_option("kernel_count")):
+        ctx.set_option("kernel", k)
+        assert (ctx.trace_rays(rays) == want).all(), k
+    ctx.set_option("kernel", -1)
+    # an ordinary scene installed on the device: finite, ordered, enclosed -> the private wide copy exists
+    sc = scenes.terrain(32, seed=2)
+    v, i = sc.flat()
+    api.bvh_build_device(ctx, v, 8, i, sc.triangle_count, install=True, want_packed=False)
+    assert ctx.get_option("bvh_finite") == 1 and ctx.get_option("bvh_enclosed") == 1 and ctx.get_option("wide_nodes") > 0

@@ -717,3 +717,36 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
         ctx.set_option("packet_budget", 16)
         ctx.set_option("packet_share", 4)
         ctx.set_option("block_waves", 1)
+
+
+def test_plain_c_caller_of_the_consumer_seam(tmp_path):
+    """A C99 program (tests/c/seam2_gpu.c) that does what a replacement of renderShadowMaskCompute does
+    (RayTracedShadows.cpp:570-595): rts_ctx_create -> rts_ctx_set_bvh -> device buffers -> rts_trace_shadow_mask_device ->
+    read back, for every kernel variant, against the committed golden masks of tests/golden/cornell_128.npz (the
+    reference's directional light and the point light).  Compiled here with the box's C compiler."""
+    import shutil
+    import struct
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler on this box")
+    g = np.load(os.path.join(GOLD, "cornell_128.npz"))
+    H, W = g["mask_dir"].shape
+    packed = np.ascontiguousarray(g["packed"], np.uint32).reshape(-1, 4)
+    blob = tmp_path / "cornell_128.bin"
+    with open(blob, "wb") as fh:
+        fh.write(struct.pack("<3I", W, H, packed.shape[0]))
+        fh.write(packed.tobytes())
+        fh.write(np.ascontiguousarray(g["constants"], np.float32).tobytes())
+        fh.write(np.ascontiguousarray(g["positions"], np.float32).tobytes())
+        fh.write(np.ascontiguousarray(g["light_point"], np.float32).tobytes())
+        fh.write(np.ascontiguousarray(g["mask_dir"], np.uint8).tobytes())
+        fh.write(np.ascontiguousarray(g["mask_point"], np.uint8).tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "seam2_gpu")
+    libdir = os.path.dirname(api.lib_path())
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "seam2_gpu.c"), "-o", exe, "-L", libdir, "-lrts", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe, str(blob)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok ") == 2 * (1 + api.ShadowContext(0).get_option("kernel_count"))

@@ -114,6 +114,19 @@ def test_host_combine_pass_equals_the_oracles_restatement_of_combine_frag():
         assert want.max() > 100 and len(np.unique(want)) > 8
 
 
+def test_device_builder_wrapper_rejects_malformed_geometry_before_calling_c():
+    """the ctypes view must not hand C a 0-d array or too few indices (C reads 3 * prim_count words)."""
+    verts = np.zeros((6, 8), np.float32)
+    with pytest.raises(ValueError):
+        api.bvh_build_device(None, verts, 8, np.array(7, np.uint32), 2)            # a 0-d array is neither an index array nor a pointer
+    with pytest.raises(ValueError):
+        api.bvh_build_device(None, verts, 8, np.arange(5, dtype=np.uint32), 2)     # 5 indices for 2 triangles
+    with pytest.raises(ValueError):
+        api.bvh_build_device(None, (0, 48), 8, np.arange(6, dtype=np.uint32), 2)   # a null device pointer
+    with pytest.raises(ValueError):
+        api.bvh_build_device(None, np.float32(1.0), 8, np.arange(6, dtype=np.uint32), 2)
+
+
 def test_bvh_blob_round_trip(tmp_path):
     wl = workloads.prepare("cornell", 8, 8, via_obj=False)
     path = api.save_bvh(str(tmp_path / "c.bvh"), wl.packed)
