@@ -147,14 +147,25 @@ int rts_ctx_create(int device_ordinal, rts_ctx** out);
 int rts_ctx_destroy(rts_ctx* ctx);
 
 /* == Gfx_CreateBuffer(Storage, stride 16, count, m_packedNodes.data()) (cpp:1039-1044).
- * Validates (structure, finiteness, box ordering) and copies H2D once; the device copy is the same Appendix-A bytes. */
+ * Validates the structure on the host, copies H2D once (the device copy is the same Appendix-A bytes), then decides on
+ * the device what the kernels may assume (finite, ordered, enclosing boxes) and derives the private copy of kernel 8. */
 int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
 
 /* Tuning knobs.  Results never depend on any of them (tests/test_gpu_parity.py).  Unknown key or bad value ->
  * RTS_ERR_INVALID_ARG.
  *   "kernel"        -1 = auto (default: packet kernel for >= 256 K pixels, variant 7 below); 0 straight,
  *                   1 while-while, 2 postpone, 3 packet (8x8 px / wave), 4 packet2 (16x8), 5 packet4 (16x16),
- *                   6 packet + successor prefetch, 7 lane-per-ray with work sharing.  get "kernel_count" = 8.
+ *                   6 packet + successor prefetch, 7 lane-per-ray with work sharing, 8 WIDE packet (a private copy of the
+ *                   stream with four boxes per node: one dependent fetch decides two levels of the reference's walk; a
+ *                   stream without a private copy runs 3), 9 the same with the loop compiled instead of hand-written.
+ *                   get "kernel_count" = 10.  rts_ctx_autotune picks between 3, 8 and 7 by timing them on the frame.
+ *   "wide_copy"     1 (default): derive the private copy for kernel 8 whenever a stream is installed (on the device,
+ *                   about 0.2 KB per triangle; needs a finite stream of ordered, enclosing boxes, at most 512 levels deep,
+ *                   at most 2^24 triangles -- otherwise there simply is none); 0: never
+ *   "wide_lane"     1 (default): a dissolved wide packet continues lane per ray over the wide nodes (a 16-entry stack per
+ *                   lane in LDS); 0: over the stream, stackless
+ *   "soft_split"    1 (default): soft shadows (nsamples > 1) with kernel 3 or 8 run 4 waves per tile, each a quarter of the
+ *                   samples (the counts meet in LDS); 0: one wave walks a pixel's samples one after the other
  *   "packet_budget" side-steps between two coherence checks of a packet (default 16)
  *   "packet_share"  a packet dissolves when it picks up fewer than share/16 of its live rays per side-step (default 4)
  *   "block_waves"   waves per workgroup of the packet kernels: 1 (default) or 4
@@ -164,7 +175,10 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *                   where the scene's long rays are: profiles/r02/row_order_sweep.log)
  *   "lds_pad"       experiment: extra dynamic LDS bytes per one-wave packet workgroup (throttles occupancy; default 0)
  *   "wave_stats"    diagnostics, see rts_ctx_read_wave_stats
- *   get only: "bvh_finite", "bvh_ordered" (which slab-test forms the uploaded stream allows) */
+ *   "clock_probe"   diagnostics, see rts_ctx_read_clock_probe
+ *   "builder_scratch" set 0: release the working memory the GPU builders keep between builds; get: MiB held
+ *   get only: "bvh_finite", "bvh_ordered", "bvh_enclosed" (what the installed stream allows: decided by one kernel over all
+ *   nodes at upload / adoption), "wide_nodes", "wide_levels" (size of the private copy, 0 = none) */
 int rts_ctx_set_option(rts_ctx* ctx, const char* key, int value);
 int rts_ctx_get_option(rts_ctx* ctx, const char* key, int* value);
 

@@ -851,6 +851,13 @@ static void wideSlots(const u32* bvh, u32 n, u32 root, int d, std::vector<WSlot>
 }
 }
 
+// Optional per-tile output of the next orc_wide_packet_sim call (tile t = by * (W / 8) + bx): nodes entered, box tests,
+// member lanes summed over those tests.  NULL switches it off.
+static uint32_t* g_tileSteps = nullptr; static uint32_t* g_tileTests = nullptr; static uint32_t* g_tileLanes = nullptr;
+extern "C" void orc_wide_packet_sim_per_tile(uint32_t* steps, uint32_t* tests, uint32_t* lanes) {
+    g_tileSteps = steps; g_tileTests = tests; g_tileLanes = lanes;
+}
+
 extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constants, const void* light_v,
                                     const float* positions, uint32_t W, uint32_t H, int depth, uint32_t histStep,
                                     uint64_t* out, uint64_t* hist) {
@@ -911,6 +918,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                 if (anyHit(bvh, o[l], tm[l], d[l], nullptr, nullptr)) expect |= 1ull << l;
             }
             uint64_t occluded = 0, mySteps = 0;
+            const uint64_t boxT0 = boxT, boxLanes0 = boxLanes;
             auto box = [&](u32 n, u32 l) {
                 const u32* a = bvh + (size_t)n * 8;
                 V3 pmin = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, pmax = { u2f(a[4]), u2f(a[5]), u2f(a[6]) };
@@ -986,6 +994,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
             }
             mism += __builtin_popcountll((occluded ^ expect) & live);
             steps += mySteps; sq += mySteps * mySteps; if (mySteps > longest) longest = mySteps; ++tiles;
+            if (g_tileSteps) { g_tileSteps[t] = (uint32_t)mySteps; g_tileTests[t] = (uint32_t)(boxT - boxT0); g_tileLanes[t] = (uint32_t)(boxLanes - boxLanes0); }
             histLoc[std::min<uint64_t>(63, mySteps / (histStep ? histStep : 1))]++;
         }
 #ifdef _OPENMP

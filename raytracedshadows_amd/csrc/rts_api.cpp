@@ -610,7 +610,9 @@ int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light,
                      uint32_t H, uint8_t* d_mask, int* chosen, float* ms_out) {
     if (!c || !k || !d_positions || !d_mask) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
-    const int candidates[3] = { rts::V_PACKET, rts::V_WIDE, rts::V_SHARE };
+    // (the wide kernel first, and a later candidate must beat the best by 2 %: at equal frame time the wide kernel's waves
+    //  are shorter, which is what a striped multi-GPU frame needs -- tools/stripe_scaling.py)
+    const int candidates[3] = { rts::V_WIDE, rts::V_PACKET, rts::V_SHARE };
     const int before = c->variant;
     int best = before;
     float bestMs = 1e30f;
@@ -630,7 +632,7 @@ int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light,
             if (i >= 0) times[i] = ms;
         }
         for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
-        if (times[2] < bestMs) { bestMs = times[2]; best = v; }
+        if (times[2] < bestMs * 0.98f) { bestMs = times[2]; best = v; }
     }
     c->variant = best;
     if (chosen) *chosen = best;

@@ -17,4 +17,4 @@ with api.ShadowContext(0) as ctx:
         seed += 1
         if (seed - first) % 20 == 0:
             print(f"{seed - first} random cases ok ({time.time() - t0:.0f}s)", flush=True)
-print(f"soak: seeds {first}..{seed - 1} all bit-exact ({seed - first} cases x 4 lights x 8 kernels, {time.time() - t0:.0f}s)")
+print(f"soak: seeds {first}..{seed - 1} all bit-exact ({seed - first} cases x 5 lights x 10 kernels, random knobs, {time.time() - t0:.0f}s)")

@@ -33,19 +33,23 @@ with api.ShadowContext(0) as ctx:
         k = api.RayTracingConstants.make(eye, [0.3, 0.8, 0.5], W, H)
         spp = int(rs.choice([1, 1, 1, 3, 16]))
         where = (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32) if rs.rand() < 0.5 else (hi + 5).astype(np.float32)
-        light = api.Light.make(api.Light.POINT, where, scenes.jitter_offsets(spp, 0.5, cases) if spp > 1 else None) if rs.rand() < 0.8 else None
+        table = int(rs.choice([0, 0, 64])) if spp > 1 else 0                 # per-pixel jitter on a third of the soft frames
+        light = api.Light.make(api.Light.POINT, where, scenes.jitter_offsets(max(spp, table), 0.5, cases) if spp > 1 else None,
+                               nsamples=spp if spp > 1 else None) if rs.rand() < 0.8 else None
         want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(light, k), pos, W, H)
         ctx.set_bvh(packed)
         d_pos, d_mask = ctx.malloc(pos.nbytes), ctx.malloc(W * H)
         ctx.h2d(d_pos, pos)
         try:
-            for kernel in (-1, 3, 4, 5, 6, 7):
+            for kernel in (-1, 3, 4, 7, 8, 9):
                 ctx.set_option("kernel", kernel)
                 ctx.set_option("packet_budget", int(rs.choice([1, 4, 16, 40])))
                 ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
                 ctx.set_option("block_waves", int(rs.choice([1, 4])))
                 ctx.set_option("xcd_swizzle", int(rs.randint(0, 2)))
                 ctx.set_option("row_order", int(rs.randint(0, 3)))
+                ctx.set_option("wide_lane", int(rs.randint(0, 2)))
+                ctx.set_option("soft_split", int(rs.randint(0, 2)))
                 got = np.full((H, W), 7, np.uint8)
                 ctx.h2d(d_mask, got)
                 n = int(rs.choice([1, 1, 2, 3, 5]))
@@ -61,9 +65,9 @@ with api.ShadowContext(0) as ctx:
                 assert bad == 0, (cases, sc.name, producer, W, H, kernel, spp, n, bad)
         finally:
             ctx.free(d_pos); ctx.free(d_mask)
-            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0)):
+            for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0), ("wide_lane", 1), ("soft_split", 1)):
                 ctx.set_option(key, v)
         cases += 1
         if cases % 5 == 0:
             print(f"{cases} big cases ok ({time.time() - t0:.0f}s)", flush=True)
-print(f"soak_big: {cases} random large frames x 6 kernels (random knobs, stripes, 1-16 samples, host- and GPU-built streams) all bit-exact ({time.time() - t0:.0f}s)")
+print(f"soak_big: {cases} random large frames x 6 kernels incl. both wide ones (random knobs, stripes, 1-16 samples, per-pixel jitter, host- and GPU-built streams) all bit-exact ({time.time() - t0:.0f}s)")

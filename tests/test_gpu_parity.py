@@ -699,7 +699,9 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
     lights = [None,
               api.Light.make(api.Light.POINT, (lo + (hi - lo) * rs.random_sample(3)).astype(np.float32)),   # inside the scene
               api.Light.make(api.Light.DIRECTIONAL, [0, 1, 0]),                                                # axis-parallel: EXACT path
-              api.Light.make(api.Light.POINT, hi + 5, scenes.jitter_offsets(int(rs.randint(2, 9)), 0.7, seed))]
+              api.Light.make(api.Light.POINT, hi + 5, scenes.jitter_offsets(int(rs.randint(2, 9)), 0.7, seed)),
+              api.Light.make(api.Light.POINT, hi + 5, scenes.jitter_offsets(int(rs.randint(9, 65)), 0.7, seed),
+                             nsamples=int(rs.randint(2, 9)))]                                                  # per-pixel jitter
     ctx.set_bvh(packed)
     try:
         for light in lights:
@@ -709,14 +711,14 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                 ctx.set_option("packet_budget", int(rs.choice([1, 2, 8, 50])))
                 ctx.set_option("packet_share", int(rs.choice([0, 2, 4, 9, 16])))
                 ctx.set_option("block_waves", int(rs.choice([1, 4])))
+                ctx.set_option("wide_lane", int(rs.randint(0, 2)))
+                ctx.set_option("soft_split", int(rs.randint(0, 2)))
                 got = ctx.trace_shadow_mask(k, pos, W, H, light=light)
                 bad = int((got != want).sum())
                 assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
     finally:
-        ctx.set_option("kernel", -1)
-        ctx.set_option("packet_budget", 16)
-        ctx.set_option("packet_share", 4)
-        ctx.set_option("block_waves", 1)
+        for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("wide_lane", 1), ("soft_split", 1)):
+            ctx.set_option(key, v)
 
 
 def test_plain_c_caller_of_the_consumer_seam(tmp_path):

@@ -6,23 +6,34 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gputests.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/gputests.log; tail -3 $OUT/gputests.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-# the driver's command, then the long form
-timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_city4k_20_5.json 2> $OUT/bench_city4k_20_5.err; echo "bench 20/5 rc=$?"; cut -c1-260 $OUT/bench_city4k_20_5.json
-timeout -k 10 400 python bench.py --save-counters $OUT/counters_city_4k.json > $OUT/bench_city4k.json 2> $OUT/bench_city4k.err; echo "bench rc=$?"
-for CFG in courtyard_4k atrium_1080p cornell_256 city_4k_soft16 courtyard_4k_soft16; do
-  timeout -k 10 400 python bench.py --config $CFG > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err; echo "bench $CFG rc=$?"; cut -c1-200 $OUT/bench_$CFG.json
+# the driver's command (headline + the secondary workloads in one line), then the long form with the counters saved
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $OUT/bench_city4k_20_5.json 2> $OUT/bench_city4k_20_5.err; echo "bench 20/5 rc=$?"; cut -c1-260 $OUT/bench_city4k_20_5.json
+timeout -k 10 500 python bench.py --no-secondary --save-counters $OUT/counters_city_4k.json > $OUT/bench_city4k.json 2> $OUT/bench_city4k.err; echo "bench rc=$?"
+for CFG in courtyard_4k atrium_1080p cornell_256 city_4k_soft16 courtyard_4k_soft16 city_4k_soft16_pp courtyard_4k_soft16_pp city_4k_directional; do
+  timeout -k 10 500 python bench.py --config $CFG > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err; echo "bench $CFG rc=$?"; cut -c1-200 $OUT/bench_$CFG.json
 done
-# multi-rank flow on the one device (2 and 4 ranks share GPU 0): striped frame, default kernel
+# the two packet families side by side on the three scenes (same protocol, kernel forced)
+for CFG in city_4k courtyard_4k atrium_1080p; do for K in 3 8; do
+  timeout -k 10 300 python bench.py --config $CFG --kernel $K --no-secondary --no-pmc --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$CFG', d['config']['kernel'], d['value'], 'Mrays/s', d['config']['ms_per_frame_gpu_median'], 'ms', d['roofline']['shader_clock_mhz'], 'MHz')" >> $OUT/packet_vs_wide_ab.log
+done; done; cat $OUT/packet_vs_wide_ab.log
+# multi-rank flow on the one device (2 and 4 ranks share GPU 0): striped frame
 for N in 2 4; do
   RTS_BENCH_SINGLE_DEVICE=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2955$N bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_${N}rank_shared_device.json 2> $OUT/bench_${N}rank_shared_device.err; echo "bench $N ranks rc=$?"
 done
 # rocprofv3 kernel trace + stats of the same command (probes off: only the timed kernel runs)
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace_bench.err); echo "trace rc=$?"
+KID=$(python -c "import json; print({'shadowMaskPacketKernel<1,wide>': 8}.get(json.load(open('$OUT/bench_city4k.json'))['config']['kernel'], 3))")
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --kernel $KID --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace_bench.err); echo "trace rc=$?"
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/city4k_kernel_stats.csv \;
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_courtyard -- python3 $REPO/bench.py --config courtyard_4k --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_courtyard.json 2> $OUT/trace_bench_courtyard.err); echo "trace courtyard rc=$?"
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_courtyard -- python3 $REPO/bench.py --config courtyard_4k --kernel 8 --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_courtyard.json 2> $OUT/trace_bench_courtyard.err); echo "trace courtyard rc=$?"
 find $OUT/trace_courtyard -name "*kernel_stats.csv" -exec cp {} $OUT/courtyard4k_kernel_stats.csv \;
 rm -rf $OUT/trace $OUT/trace_courtyard
-timeout -k 10 300 python tools/floor_analysis.py > $OUT/floor_analysis_city4k.log 2>&1
-timeout -k 10 300 python tools/dispatch_floor.py > $OUT/dispatch_floor.log 2>&1
-timeout -k 10 400 python tests/experiments/soak.py 180 5000 > $OUT/soak_randomised_parity.log 2>&1; tail -1 $OUT/soak_randomised_parity.log
+for K in 3 8; do for CFG in city_4k courtyard_4k atrium_1080p; do
+  timeout -k 10 300 python tools/floor_analysis.py --config $CFG --kernel $K 2>&1 | grep -v "one-triangle" | grep -A6 "BVH\]" > $OUT/floor_analysis_${CFG}_kernel$K.log
+  timeout -k 10 300 python tools/long_waves.py --config $CFG --kernel $K 2>&1 | tail -2 > $OUT/long_waves_${CFG}_kernel$K.log
+done; done
+for a in "city_4k 3" "city_4k 8" "courtyard_4k 3" "courtyard_4k 8" "city_4k_soft16 3"; do set -- $a
+  timeout -k 10 300 python tools/stripe_scaling.py --config $1 --kernel $2 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_$1_kernel$2.log; tail -1 $OUT/stripe_scaling_$1_kernel$2.log | cut -c1-60; done
+timeout -k 10 300 python tools/stripe_scaling.py --config city_4k_soft16 --kernel 3 --options soft_split=0 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_city_4k_soft16_kernel3_no_split.log
+timeout -k 10 200 tools/microbench/node_fetch > $OUT/node_fetch_microbench.log 2>&1; cat $OUT/node_fetch_microbench.log
 timeout -k 10 300 python tools/host_path_timing.py > $OUT/host_path_timing.log 2>&1; tail -2 $OUT/host_path_timing.log

@@ -16,6 +16,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="city_4k")
     ap.add_argument("--band", type=int, default=32)
+    ap.add_argument("--kernel", type=int, default=-2, help="kernel id; -1 = library default; -2 = rts_ctx_autotune on the full frame (as bench.py does)")
+    ap.add_argument("--options", default="", help="comma list of key=value context options")
     args = ap.parse_args()
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config, cache=True)
@@ -24,6 +26,15 @@ def main():
         ctx.set_bvh(wl.packed)
         d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
         ctx.h2d(d_pos, wl.positions)
+        for kv in filter(None, args.options.split(",")):
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
+        if args.kernel == -2:
+            for _ in range(100):
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            print(f"[{args.config}] autotune: kernel {ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)}")
+        else:
+            ctx.set_option("kernel", args.kernel)
         base = None
         for n in (1, 2, 4, 8):
             worst, times = 0.0, []
