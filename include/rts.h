@@ -218,6 +218,10 @@ int rts_device_free(rts_ctx* ctx, void* d_ptr);
 int rts_memcpy_h2d(rts_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int rts_memcpy_d2h(rts_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int rts_stream_synchronize(rts_ctx* ctx, void* stream);
+/* A stream of the context's device for the `stream` arguments above (a renderer passes its own hipStream_t).  Dispatches on
+ * different streams may overlap: with two frames in flight the tail of one frame's dispatch runs beside the next one's. */
+int rts_stream_create(rts_ctx* ctx, void** stream);
+int rts_stream_destroy(rts_ctx* ctx, void* stream);
 /* hipEvent pair on `stream` == Gfx_BeginTimer/EndTimer(Timestamp_Shadows) (cpp:572,594).
  * rts_timer_end records the stop event; rts_timer_elapsed_ms synchronises on it. */
 int rts_timer_begin(rts_ctx* ctx, void* stream);

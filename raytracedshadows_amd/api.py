@@ -147,6 +147,8 @@ _sig("rts_ctx_set_tile_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_wave_realtime", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_ctx_read_clock_probe", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_sig("rts_stream_create", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_sig("rts_stream_destroy", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
      C.POINTER(C.c_int), C.POINTER(C.c_float))
 _sig("rts_timer_mark", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
@@ -350,6 +352,14 @@ class ShadowContext:
                "rts_trace_rays_device")
 
     # -- plumbing ---------------------------------------------------------------------------
+    def stream_create(self):
+        s = C.c_void_p()
+        _check(_lib.rts_stream_create(self._h, C.byref(s)), "rts_stream_create")
+        return s.value
+
+    def stream_destroy(self, stream):
+        _check(_lib.rts_stream_destroy(self._h, C.c_void_p(stream)), "rts_stream_destroy")
+
     def malloc(self, nbytes):
         p = C.c_void_p()
         _check(_lib.rts_device_malloc(self._h, C.byref(p), nbytes), "rts_device_malloc")

@@ -481,6 +481,20 @@ int rts_device_mem_info(rts_ctx* c, size_t* free_bytes, size_t* total_bytes) {
     if (total_bytes) *total_bytes = t;
     return RTS_OK;
 }
+int rts_stream_create(rts_ctx* c, void** stream) {
+    if (!c || !stream) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    hipStream_t s = nullptr;
+    RTS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return RTS_OK;
+}
+int rts_stream_destroy(rts_ctx* c, void* stream) {
+    if (!c || !stream) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    RTS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return RTS_OK;
+}
 int rts_stream_synchronize(rts_ctx* c, void* stream) {
     if (!c) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
