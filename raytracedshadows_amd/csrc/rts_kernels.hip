@@ -1120,9 +1120,10 @@ void shadowMaskPacketKernel(TraceParams p) {
         p.waveRealtime[slot * 4] = rStart;
         p.waveRealtime[slot * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         p.waveRealtime[slot * 4 + 2] = tReady - tStart;      // clocks from wave start to "first ray ready"
-        uint32_t xcc;
+        uint32_t xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.waveRealtime[slot * 4 + 3] = xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));       // wave slot, SIMD, CU, SE ... of this wave
+        p.waveRealtime[slot * 4 + 3] = ((uint64_t)hwid << 32) | xcc;
         // dissolved flag | lane-per-ray iterations after the dissolve | clocks from start to the dissolve
         o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
                ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);
