@@ -846,23 +846,43 @@ __global__ void setParentsKernel(Lbvh b, const uint32_t* pairs, uint32_t nPairs,
     if (i == 0) b.parent[root] = END;
 }
 
-// Pre-order index of a node = sum over its ancestors of (1 + size of the sibling subtree visited before it).
-__global__ void emitKernel(Lbvh b, const uint32_t* order, uint32_t* packed) {
+// Pre-order index of a node = sum over the node and its ancestors of w = 1 + (size of the sibling subtree visited before
+// it).  Computed by pointer doubling -- after k rounds acc[i] covers the 2^k nearest ancestors-or-self, up[i] is the 2^k-th
+// ancestor -- so the cost is N log(depth) whatever the shape of the tree (a walk to the root per node was N * depth: tens of
+// seconds for a chain of 10^5 equal boxes).
+__global__ void preorderInitKernel(Lbvh b, uint32_t* acc, uint32_t* up) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t P = b.P, N = 2 * P - 1;
+    if (id >= N) return;
+    const uint32_t par = b.parent[id];
+    uint32_t w = 0;
+    if (par != END) {
+        w = 1;
+        if (b.child[2 * par + 1] == id) {                        // second child: the first one's subtree comes before
+            const uint32_t first = b.child[2 * par];
+            w += first >= P - 1 ? 1u : 2u * b.leaves[first] - 1u;
+        }
+    }
+    acc[id] = w; up[id] = par;
+}
+__global__ void preorderJumpKernel(uint32_t N, const uint32_t* accIn, const uint32_t* upIn, uint32_t* accOut, uint32_t* upOut, uint32_t* unfinished) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t u = upIn[i];
+    if (u == END) { accOut[i] = accIn[i]; upOut[i] = END; return; }
+    accOut[i] = accIn[i] + accIn[u];
+    const uint32_t uu = upIn[u];
+    upOut[i] = uu;
+    if (uu != END) *unfinished = 1u;
+}
+
+__global__ void emitKernel(Lbvh b, const uint32_t* order, const uint32_t* preorder, uint32_t* packed) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t P = b.P, N = 2 * P - 1;
     if (id >= N) return;
     const bool leaf = id >= P - 1;
     const uint32_t size = leaf ? 1u : 2u * b.leaves[id] - 1u;
-    uint32_t index = 0, cur = id;
-    for (uint32_t guard = 0; guard < N && b.parent[cur] != END; ++guard) {      // (a chain of equal boxes is as deep as it is long)
-        const uint32_t par = b.parent[cur];
-        index += 1;
-        if (b.child[2 * par + 1] == cur) {                       // second child: the first one's subtree comes before
-            const uint32_t first = b.child[2 * par];
-            index += first >= P - 1 ? 1u : 2u * b.leaves[first] - 1u;
-        }
-        cur = par;
-    }
+    const uint32_t index = preorder[id];
     const uint32_t next = index + size >= N ? END : index + size;
     uint32_t* o = packed + (size_t)index * 8;
     if (leaf) {
@@ -934,6 +954,29 @@ struct DeviceArena {            // working buffers: carved out of the context's 
 
 #define LB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { arena.release(); return RTS_ERR_HIP + (int)e_; } } while (0)
 
+// pre-order indices of all nodes into one of the two acc buffers (returned); six rounds cover 64 levels, then the device says
+// whether any node still has ancestors to add
+hipError_t preorderIndices(const Lbvh& b, uint32_t* acc[2], uint32_t* up[2], uint32_t* flag, const uint32_t** result) {
+    const uint32_t N = 2 * b.P - 1;
+    const dim3 block(256), grid((N + 255) / 256);
+    hipLaunchKernelGGL(preorderInitKernel, grid, block, 0, nullptr, b, acc[0], up[0]);
+    int cur = 0;
+    for (uint32_t round = 0; round < 40; ++round) {
+        const bool look = round >= 5;
+        if (look) { hipError_t e = hipMemsetAsync(flag, 0, 4, nullptr); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(preorderJumpKernel, grid, block, 0, nullptr, N, acc[cur], up[cur], acc[cur ^ 1], up[cur ^ 1], flag);
+        cur ^= 1;
+        if (look) {
+            uint32_t unfinished = 0;
+            hipError_t e = hipMemcpy(&unfinished, flag, 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            if (!unfinished) break;
+        }
+    }
+    *result = acc[cur];
+    return hipGetLastError();
+}
+
 } // namespace
 
 extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size_t vertex_floats, uint32_t stride,
@@ -957,7 +1000,7 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
 
     DeviceArena arena;
     // every buffer of the largest path (SAH) + sort scratch; geometry that is used where it lies needs no room
-    arena.slabBytes = (vertsOn >= 0 ? 0 : vertex_floats * 4) + (idxOn >= 0 ? 0 : (size_t)P * 12) + (size_t)P * 588 + ((size_t)4 << 20);
+    arena.slabBytes = (vertsOn >= 0 ? 0 : vertex_floats * 4) + (idxOn >= 0 ? 0 : (size_t)P * 12) + (size_t)P * 620 + ((size_t)4 << 20);
     arena.slab = getenv("RTS_NO_BUILDER_SLAB") ? nullptr : (char*)rts_ctx_scratch(ctx, arena.slabBytes);   // (test hook: the no-slab path)
     if (!arena.slab) arena.slabBytes = 0;
     Lbvh b{};
@@ -975,6 +1018,8 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
     LB_HIP(arena.get(&b.nodeLo, (size_t)P * 12)); LB_HIP(arena.get(&b.nodeHi, (size_t)P * 12));
     LB_HIP(arena.get(&b.leaves, (size_t)P * 4)); LB_HIP(arena.get(&b.done, (size_t)P * 4));
     LB_HIP(arena.get(&b.pending, 16)); LB_HIP(arena.get(&b.flags, 16));
+    uint32_t* preAcc[2]; uint32_t* preUp[2];                     // pre-order numbering by pointer doubling (emit)
+    for (int i = 0; i < 2; ++i) { LB_HIP(arena.get(&preAcc[i], (size_t)P * 8)); LB_HIP(arena.get(&preUp[i], (size_t)P * 8)); }
     b.verts = d_verts; b.indices = d_idx;
 
     if (vertsOn < 0) LB_HIP(hipMemcpy(d_verts, vertices, vertex_floats * 4, hipMemcpyHostToDevice));
@@ -1072,7 +1117,9 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             std::swap(s.segB, s.segBOut); std::swap(s.segE, s.segEOut); std::swap(s.posAxis, s.posAxisOut);
             { uint32_t* t = s.tileLivePrev; s.tileLivePrev = s.tileLive; s.tileLive = s.tileLiveOut; s.tileLiveOut = t; }
         }
-        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, identity, (uint32_t*)d_packed);
+        const uint32_t* pre = nullptr;
+        LB_HIP(preorderIndices(b, preAcc, preUp, b.flags + 3, &pre));
+        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, identity, pre, (uint32_t*)d_packed);
     } else if (P > 1) {
         hipLaunchKernelGGL(mortonKernel, gridP, block, 0, nullptr, b);
         size_t tempBytes = 0;
@@ -1154,7 +1201,9 @@ extern "C" int rts_bvh_build_device_ex(rts_ctx* ctx, const float* vertices, size
             LB_HIP(hipMemcpy(&left, b.pending, 4, hipMemcpyDeviceToHost));
             if (left != 0) { arena.release(); return RTS_ERR_BAD_BVH; }
         }
-        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, sortedOrder, (uint32_t*)d_packed);
+        const uint32_t* pre = nullptr;
+        LB_HIP(preorderIndices(b, preAcc, preUp, b.flags + 3, &pre));
+        hipLaunchKernelGGL(emitKernel, gridN, block, 0, nullptr, b, sortedOrder, pre, (uint32_t*)d_packed);
     } else {
         hipLaunchKernelGGL(emitSingleKernel, dim3(1), dim3(64), 0, nullptr, b, (uint32_t*)d_packed);
     }
