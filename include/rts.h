@@ -162,8 +162,8 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *   "wide_copy"     1 (default): derive the private copy for kernel 8 whenever a stream is installed (on the device,
  *                   about 0.2 KB per triangle; needs a finite stream of ordered, enclosing boxes, at most 512 levels deep,
  *                   at most 2^24 triangles -- otherwise there simply is none); 0: never
- *   "wide_lane"     1 (default): a dissolved wide packet continues lane per ray over the wide nodes (a 16-entry stack per
- *                   lane in LDS); 0: over the stream, stackless
+ *   "wide_lane"     0 (default): a dissolved wide packet continues lane per ray over the stream, stackless; 1: over the wide
+ *                   nodes with a 16-entry stack per lane in LDS (4 KB per wave: a CU then holds 28 instead of 32 waves)
  *   "soft_split"    1 (default): soft shadows (nsamples > 1) with kernel 3 or 8 run 4 waves per tile, each a quarter of the
  *                   samples (the counts meet in LDS); 0: one wave walks a pixel's samples one after the other
  *   "packet_budget" side-steps between two coherence checks of a packet (default 16)

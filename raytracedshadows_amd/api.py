@@ -435,10 +435,12 @@ class ShadowContext:
         """Shader clock held during the launches since set_option("clock_probe", rows) (the timed launches themselves)."""
         out = np.zeros((rows, 4), np.uint64)
         _check(_lib.rts_ctx_read_clock_probe(self._h, _ptr(out), rows), "rts_ctx_read_clock_probe")
-        ok = (out[:, 1] > out[:, 0]) & (out[:, 3] > out[:, 2])
+        self.last_clock_probe = out.copy()                      # (tools: wave lifetimes, hardware slots)
+        end = out[:, 1] & np.uint64(0x0000FFFFFFFFFFFF)         # the top 16 bits carry the wave's hardware slot (HW_ID)
+        ok = (end > out[:, 0]) & (out[:, 3] > out[:, 2])
         if not ok.any():
             return None
-        return float((out[ok, 1] - out[ok, 0]).astype(np.float64).sum() / (out[ok, 3] - out[ok, 2]).astype(np.float64).sum() * 100.0)
+        return float((end[ok] - out[ok, 0]).astype(np.float64).sum() / (out[ok, 3] - out[ok, 2]).astype(np.float64).sum() * 100.0)
 
     def measure_shader_clock_mhz(self, trace, waves, launches=8):
         """Clock the chip holds while `trace()` (one dispatch of a packet kernel with `waves` one-wave workgroups) runs

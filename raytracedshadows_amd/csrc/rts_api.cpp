@@ -44,7 +44,7 @@ struct rts_ctx {
     uint32_t wideCount = 0, wideLevels = 0;
     bool bvhEnclosed = false;                // pre-order binary tree whose boxes enclose their children's (validateKernel)
     int wideCopy = 1;                        // option "wide_copy": build the private copy at upload
-    int wideLane = 1;                        // option "wide_lane": dissolved wide packets walk the wide nodes lane per ray
+    int wideLane = 0;                        // option "wide_lane": dissolved wide packets walk the wide nodes lane per ray (LDS stacks: 28 waves per CU)
     int softSplit = 1;                       // option "soft_split": soft shadows with 4 waves per tile (samples side by side)
     uint32_t pixelBase = 0;                  // set around a host-pointer stripe (see rts_trace_shadow_mask)
     uint64_t* d_clockProbe = nullptr; size_t clockProbeRows = 0;    // option "clock_probe"

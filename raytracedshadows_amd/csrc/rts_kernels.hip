@@ -886,8 +886,10 @@ __device__ __forceinline__ bool traverseWide(const TraceParams& p, const NodeStr
         uint64_t occ = 0;
         const uint64_t liveU = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(liveMask >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)liveMask);
+        // (tmax is a property of the light, not of the ray: comp:145 / the point-light extension)
+        const float tmaxUniform = p.lightType == 0 ? 1e9f : 1.0f;
         const uint32_t st = wideDescend(form, (const void*)(uintptr_t)uniform64(p.wide), (const void*)(uintptr_t)uniform64(p.tris), r, w,
-                                        liveU, occ, sp, stRef, stLo, stHi, p.packetBudget, p.packetBudget * p.packetShare);
+                                        tmaxUniform, liveU, occ, sp, stRef, stLo, stHi, p.packetBudget, p.packetBudget * p.packetShare);
         if (dissolved) *dissolved = st ? -1 : 0;
         if (st == 0) return __builtin_amdgcn_inverse_ballot_w64(occ);
         return wideDissolve(p, bvh, r, w, occ, sp, stRef, stLo, stHi, lds, laneStack, diag);
@@ -1018,7 +1020,8 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // SOFT = more than one sample per pixel: only then the G-buffer position has to stay in registers across the walk.
 // PLAIN = the everyday launch (natural tile order on a 2-D grid, one contiguous row range, no diagnostics): the scalar
 // prologue that sorts out the other cases is compiled away.
-// WIDE = the walk over the private wide nodes (K = 1, WPB = 1): 1 = the loop in assembly, 2 = the same loop compiled.
+// WIDE = the walk over the private wide nodes (K = 1, WPB = 1): 1 = the loop in assembly, 2 = the same loop compiled, 3 = 1
+// with per-lane stacks in LDS for the lane-per-ray continuation over the wide nodes (option "wide_lane").
 // SPLIT (soft shadows, K = 1, WPB = 1): SPLIT waves per workgroup work on the SAME 8x8 tile, wave w walks samples w,
 // w + SPLIT, ...; the counts meet in LDS and wave 0 stores the byte.  A pixel's samples then run side by side instead of
 // one after the other: a wave lives 1/SPLIT as long (shorter tail, finer-grained stripes).
@@ -1026,14 +1029,20 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // a band is 2^bandShift tile rows, so the frame row of a tile row is two shifts and a multiply on the scalar unit
 // instead of the general prologue with its per-lane division.
 template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false>
+// (Registers: a SIMD holds 8 waves of a kernel only up to 64 VGPRs AND 80 SGPRs including VCC / FLAT_SCRATCH / XNACK: the
+//  next granule, 96, plus the 16 the trap handler adds per wave fits 800 only 7 times -- measured with the hardware slot ids
+//  of the probe waves, DESIGN.md 4.7.  Every K = 1 instantiation is inside both limits; tools/gen_wide_asm.py budgets for it.)
 __global__ __launch_bounds__(64 * WPB * SPLIT) __attribute__((amdgpu_waves_per_eu(K == 1 ? 8 : 4)))
 void shadowMaskPacketKernel(TraceParams p) {
     static_assert(!BANDS || (PLAIN && K == 1 && WPB == 1), "the band form exists for the one-tile everyday launch only");
     static_assert(SPLIT == 1 || (K == 1 && WPB == 1 && SOFT), "samples are split over waves in the one-tile soft-shadow form only");
     __shared__ uint32_t shareSlots[WPB * SPLIT][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
-    __shared__ uint32_t laneStacks[WIDE != 0 ? WPB * SPLIT : 1][WIDE != 0 ? LANE_STACK * 64 : 1];   // per-lane stacks of the wide lane walk (4 KB per wave)
-    uint32_t* laneStack = WIDE != 0 ? laneStacks[threadIdx.x >> 6] : nullptr;
+    // per-lane stacks of the wide lane walk: 4 KB per wave -- which caps a CU at 28 one-wave workgroups instead of 32, so
+    // only the instantiations that use them (WIDE == 3: option "wide_lane") allocate them
+    constexpr bool LANE_STACKS = WIDE == 3;
+    __shared__ uint32_t laneStacks[LANE_STACKS ? WPB * SPLIT : 1][LANE_STACKS ? LANE_STACK * 64 : 1];
+    uint32_t* laneStack = LANE_STACKS ? laneStacks[threadIdx.x >> 6] : nullptr;
     __shared__ uint32_t partial[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 64 : 1];                          // per-wave counts of unoccluded samples
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx = blockIdx.x, by = dispatchRow(p, blockIdx.y);       // (PLAIN: a 2-D grid, rows in dispatchRow order)
@@ -1086,7 +1095,7 @@ void shadowMaskPacketKernel(TraceParams p) {
             asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
             tReady = __builtin_amdgcn_s_memtime();
         }
-        if constexpr (WIDE != 0) occluded[0] = traverseWide<WIDE == 1>(p, bvh, r[0], live[0], lds, laneStack, &left, &shareDiag);
+        if constexpr (WIDE != 0) occluded[0] = traverseWide<WIDE != 2>(p, bvh, r[0], live[0], lds, laneStack, &left, &shareDiag);
         else traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
@@ -1109,7 +1118,11 @@ void shadowMaskPacketKernel(TraceParams p) {
     }
     if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t* o = p.clockProbe + (size_t)(p.grid2d ? blockIdx.y : 0u) * 4;
-        o[1] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        // (the wave's hardware slot rides in the top 16 bits of the end stamp: 2^48 shader clocks are 32 hours)
+        o[1] = (__builtin_amdgcn_s_memtime() & 0x0000FFFFFFFFFFFFull) | ((uint64_t)(hwid & 0xFFFFu) << 48);
+        o[3] = __builtin_amdgcn_s_memrealtime();
     }
     if (!PLAIN && p.waveStats && lane == 0) {    // diagnostics: never read by any kernel, never part of an output
         const size_t slot = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WPB * SPLIT) + wave;
@@ -1204,6 +1217,8 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         dim3 b1(64);
         if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1, 4>), grid, dim3(256), 0, stream, p);
         else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
+        else if (p.wideLane)                        // lane-per-ray continuation over the wide nodes: the instantiation with LDS stacks
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 3>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)

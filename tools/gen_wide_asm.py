@@ -11,13 +11,16 @@ test for the lanes that hit its box and confirms triangle hits with the EXACT sl
 first inner slot becomes the next node, further ones are pushed (node, mask) on the stack that lives in three VGPRs
 (entry i in lane i; v_writelane / v_readlane through M0).
 
-Fixed scratch SGPRs (declared as clobbers), relative to SGPR_BASE = 20:
-    N[0:31]   +0..+31   the wide node: slot k = N[6k..6k+2] bboxMin, N[6k+3..6k+5] bboxMax; N[24+k] ref; N[28] own node index
-    T[0:15]   +32..+47  triangle record: v0.xyz, e0.xyz, e1.xyz, leaf node, parent's bboxMin, bboxMax (unused here: the slot has it)
-    H0..H3    +48..+55  members that hit slot k          M   +56,57  members of the current node
-    NXM       +58,59    members of the next node        NXREF +60   its ref (-1: none yet)
-    REF       +61       byte offset of the current node  SAVE +62,63 EXEC at entry
-    R         +64,+65   reject mask / temporaries (the second temporary mask is VCC)
+Fixed scratch SGPRs (declared as clobbers), relative to SGPR_BASE = 20 -- 54 of them, so that the kernel stays within
+80 SGPRs: the granule above (96) plus the 16 the trap handler adds per wave leaves room for 7 waves per SIMD, not 8
+(measured with HW_ID stamps):
+    N[0:27]   +0..+27   the wide node: slot k = N[6k..6k+2] bboxMin, N[6k+3..6k+5] bboxMax; N[24+k] ref  (dwords 28..31 of
+                        the node are not loaded: x16 + x8 + x4)
+    T[0:8]    +28..+36  triangle record: v0.xyz, e0.xyz, e1.xyz  (x8 + one dword; the rest of the record is for the lane walks)
+    H0..H3    +38..+45  members that hit slot k          M   +46,47  members of the current node
+    NXM       +48,49    members of the next node        NXREF +50   its ref (-1: none yet)
+    REF       +51       byte offset of the current node  R   +52,53  reject mask / temporaries (the second temporary mask is VCC)
+EXEC at entry is kept in lane 63 of the stack's two mask registers (the stack dissolves before entry 61 is written).
 """
 import os
 import sys
@@ -42,16 +45,20 @@ def N(i):
 
 
 def T(i):
-    return s(32 + i)
+    return s(28 + i)
+
+
+HBASE = 38
 
 
 def H(k):
-    return sp(48 + 2 * k)
+    return sp(HBASE + 2 * k)
 
 
-M, NXM, NXREF, REF, SAVE, R, R2 = sp(56), sp(58), s(60), s(61), sp(62), sp(64), "vcc"
-MLO, MHI = s(56), s(57)
-RLO, RHI = s(64), s(65)
+M, NXM, NXREF, REF, R, R2 = sp(46), sp(48), s(50), s(51), sp(52), "vcc"
+MLO, MHI = s(46), s(47)
+RLO, RHI = s(52), s(53)
+NSGPR = 54
 
 
 def lo(k, a):
@@ -139,7 +146,9 @@ def exact_box(k, octant, dst):
 
 def triangle(dst):
     """Moeller-Trumbore exactly as comp:41-59 spells it (separate mul/sub/add, dots left to right, correctly rounded
-    1/det: the sequence hipcc emits for 1.0f / x); v0 = T0-2, e0 = T3-5, e1 = T6-8.  dst = lanes of EXEC that are REJECTED."""
+    1/det: the sequence hipcc emits for 1.0f / x); v0 = T0-2, e0 = T3-5, e1 = T6-8.  dst = lanes of EXEC that are REJECTED.
+    Ten temporaries: s2 takes the registers of s1 once b1 exists, b2 / t / b1+b2 those of dd once s2 exists (the number of
+    VGPRs named by the statement decides whether a SIMD holds 8 waves of this kernel or 7)."""
     e0, e1, v0 = (T(3), T(4), T(5)), (T(6), T(7), T(8)), (T(0), T(1), T(2))
     return [
         f"v_mul_f32 %[t0], {e1[2]}, %[dy]", f"v_mul_f32 %[t1], {e1[1]}, %[dz]", "v_sub_f32 %[t0], %[t0], %[t1]",   # s1.x = d.y*e1.z - e1.y*d.z
@@ -161,32 +170,35 @@ def triangle(dst):
         f"v_subrev_f32 %[t5], {v0[0]}, %[ox]", f"v_subrev_f32 %[t6], {v0[1]}, %[oy]", f"v_subrev_f32 %[t7], {v0[2]}, %[oz]",   # dd = o - v0
         "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
         "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]",       # b1 = dot(dd, s1) * invd
-        f"v_mul_f32 %[t9], {e0[2]}, %[t6]", f"v_mul_f32 %[t10], {e0[1]}, %[t7]", "v_sub_f32 %[t9], %[t9], %[t10]",     # s2.x = dd.y*e0.z - e0.y*dd.z
-        f"v_mul_f32 %[t10], {e0[0]}, %[t7]", f"v_mul_f32 %[t11], {e0[2]}, %[t5]", "v_sub_f32 %[t10], %[t10], %[t11]",  # s2.y = dd.z*e0.x - e0.z*dd.x
-        f"v_mul_f32 %[t11], {e0[1]}, %[t5]", f"v_mul_f32 %[t12], {e0[0]}, %[t6]", "v_sub_f32 %[t11], %[t11], %[t12]",  # s2.z = dd.x*e0.y - e0.x*dd.y
-        "v_mul_f32 %[t12], %[dx], %[t9]", "v_mul_f32 %[t13], %[dy], %[t10]", "v_add_f32 %[t12], %[t12], %[t13]",
-        "v_mul_f32 %[t13], %[dz], %[t11]", "v_add_f32 %[t12], %[t12], %[t13]", "v_mul_f32 %[t12], %[t12], %[t4]",  # b2 = dot(d, s2) * invd
-        f"v_mul_f32 %[t13], {e1[0]}, %[t9]", f"v_mul_f32 %[t14], {e1[1]}, %[t10]", "v_add_f32 %[t13], %[t13], %[t14]",
-        f"v_mul_f32 %[t14], {e1[2]}, %[t11]", "v_add_f32 %[t13], %[t13], %[t14]", "v_mul_f32 %[t13], %[t13], %[t4]",  # t = dot(e1, s2) * invd
-        "v_add_f32 %[t14], %[t8], %[t12]",                                                                          # b1 + b2
+        f"v_mul_f32 %[t0], {e0[2]}, %[t6]", f"v_mul_f32 %[t3], {e0[1]}, %[t7]", "v_sub_f32 %[t0], %[t0], %[t3]",       # s2.x = dd.y*e0.z - e0.y*dd.z
+        f"v_mul_f32 %[t1], {e0[0]}, %[t7]", f"v_mul_f32 %[t3], {e0[2]}, %[t5]", "v_sub_f32 %[t1], %[t1], %[t3]",       # s2.y = dd.z*e0.x - e0.z*dd.x
+        f"v_mul_f32 %[t2], {e0[1]}, %[t5]", f"v_mul_f32 %[t3], {e0[0]}, %[t6]", "v_sub_f32 %[t2], %[t2], %[t3]",       # s2.z = dd.x*e0.y - e0.x*dd.y
+        "v_mul_f32 %[t5], %[dx], %[t0]", "v_mul_f32 %[t6], %[dy], %[t1]", "v_add_f32 %[t5], %[t5], %[t6]",
+        "v_mul_f32 %[t6], %[dz], %[t2]", "v_add_f32 %[t5], %[t5], %[t6]", "v_mul_f32 %[t5], %[t5], %[t4]",         # b2 = dot(d, s2) * invd
+        f"v_mul_f32 %[t6], {e1[0]}, %[t0]", f"v_mul_f32 %[t7], {e1[1]}, %[t1]", "v_add_f32 %[t6], %[t6], %[t7]",
+        f"v_mul_f32 %[t7], {e1[2]}, %[t2]", "v_add_f32 %[t6], %[t6], %[t7]", "v_mul_f32 %[t6], %[t6], %[t4]",       # t = dot(e1, s2) * invd
+        "v_add_f32 %[t7], %[t8], %[t5]",                                                                             # b1 + b2
         # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51)
         f"v_cmp_gt_f32 {dst}, 0, %[t8]",
         f"v_cmp_lt_f32 {R2}, 1.0, %[t8]", f"s_or_b64 {dst}, {dst}, {R2}",
-        f"v_cmp_gt_f32 {R2}, 0, %[t12]", f"s_or_b64 {dst}, {dst}, {R2}",
-        f"v_cmp_lt_f32 {R2}, 1.0, %[t14]", f"s_or_b64 {dst}, {dst}, {R2}",
-        f"v_cmp_gt_f32 {R2}, 0, %[t13]", f"s_or_b64 {dst}, {dst}, {R2}",
-        f"v_cmp_lt_f32 {R2}, %[tm], %[t13]", f"s_or_b64 {dst}, {dst}, {R2}"]
+        f"v_cmp_gt_f32 {R2}, 0, %[t5]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_lt_f32 {R2}, 1.0, %[t7]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_gt_f32 {R2}, 0, %[t6]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"v_cmp_lt_f32 {R2}, %[tm], %[t6]", f"s_or_b64 {dst}, {dst}, {R2}"]          # (tmax is the same for every ray of a launch: an SGPR)
 
 
 def loop(octant):
-    L = [f"s_mov_b64 {SAVE}, exec",
+    L = [f"s_mov_b64 {R}, exec",
+         f"v_writelane_b32 %[vlo], {RLO}, 63",
+         f"v_writelane_b32 %[vhi], {RHI}, 63",
          f"s_mov_b32 {REF}, 0",                                  # the root's wide node
          f"s_andn2_b64 {M}, %[live], %[occ]",
          "s_cbranch_scc0 90f",
          # ---- one node --------------------------------------------------------------------------------------------
          "1:",
          f"s_load_dwordx16 s[{BASE}:{BASE + 15}], %[wb], {REF}",
-         f"s_load_dwordx16 s[{BASE + 16}:{BASE + 31}], %[wb], {REF} offset:64",
+         f"s_load_dwordx8 s[{BASE + 16}:{BASE + 23}], %[wb], {REF} offset:64",
+         f"s_load_dwordx4 s[{BASE + 24}:{BASE + 27}], %[wb], {REF} offset:96",
          "s_cmp_gt_u32 %[sp], 60",                               # a node pushes at most 3 entries; 64 fit
          "s_cbranch_scc1 80f",
          f"s_mov_b32 {NXREF}, -1",
@@ -240,24 +252,24 @@ def loop(octant):
           f"v_writelane_b32 %[vlo], {MLO}, m0",
           f"v_writelane_b32 %[vhi], {MHI}, m0",
           "s_add_u32 %[sp], %[sp], 1",
-          "s_mov_b32 %[st], 1",
+          "s_mov_b32 %[acc], 1",                                 # (the status leaves in acc)
           "s_branch 99f",
           "90:",
-          "s_mov_b32 %[st], 0",
+          "s_mov_b32 %[acc], 0",
           "s_branch 99f"]
     # ---- out of line: push slot k ----------------------------------------------------------------------------------
     for k in range(4):
         L += [f"4{k}:",
               "s_mov_b32 m0, %[sp]",
               f"v_writelane_b32 %[vref], {N(24 + k)}, m0",
-              f"v_writelane_b32 %[vlo], {s(48 + 2 * k)}, m0",
-              f"v_writelane_b32 %[vhi], {s(49 + 2 * k)}, m0",
+              f"v_writelane_b32 %[vlo], {s(HBASE + 2 * k)}, m0",
+              f"v_writelane_b32 %[vhi], {s(HBASE + 1 + 2 * k)}, m0",
               "s_add_u32 %[sp], %[sp], 1"]
         if PREFETCH:
             # the node will be popped later: ask for its two cache lines now (into two registers nobody reads; every
             # later s_waitcnt lgkmcnt(0) covers them), so that the pop finds them in the scalar cache
-            L += [f"s_load_dword {s(66)}, %[wb], {N(24 + k)}",
-                  f"s_load_dword {s(67)}, %[wb], {N(24 + k)} offset:64"]
+            L += [f"s_load_dword {s(NSGPR)}, %[wb], {N(24 + k)}",
+                  f"s_load_dword {s(NSGPR + 1)}, %[wb], {N(24 + k)} offset:64"]
         L += [f"s_branch 2{k}b"]
     # ---- out of line: leaf slot k ------------------------------------------------------------------------------------
     for k in range(4):
@@ -271,7 +283,8 @@ def loop(octant):
               f"s_andn2_b64 exec, {H(k)}, %[occ]",
               f"s_cbranch_scc0 6{k}f",
               f"s_sub_u32 {REF}, {N(24 + k)}, 1",               # (REF is free here: the node is in registers)
-              f"s_load_dwordx16 s[{BASE + 32}:{BASE + 47}], %[tb], {REF}",
+              f"s_load_dwordx8 s[{BASE + 28}:{BASE + 35}], %[tb], {REF}",
+              f"s_load_dword {T(8)}, %[tb], {REF} offset:32",
               "s_waitcnt lgkmcnt(0)"]
         L += triangle(R)
         L += [f"s_andn2_b64 exec, exec, {R}",                   # lanes whose ray hits the triangle
@@ -282,21 +295,23 @@ def loop(octant):
               f"s_branch 2{k}b"]
     L += ["99:",
           "s_waitcnt lgkmcnt(0)",                                # nothing of ours may land in SGPRs after the asm ends
-          f"s_mov_b64 exec, {SAVE}"]
+          f"v_readlane_b32 {RLO}, %[vlo], 63",
+          f"v_readlane_b32 {RHI}, %[vhi], 63",
+          f"s_mov_b64 exec, {R}"]
     return L
 
 
 def emit(octant, ind):
     lines = loop(octant)
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
-    outs = ['[sp] "+s"(sp)', '[acc] "+s"(acc)', '[budget] "+s"(budget)', '[occ] "+s"(occ)', '[st] "=&s"(st)',
+    outs = ['[sp] "+s"(sp)', '[acc] "+s"(acc)', '[budget] "+s"(budget)', '[occ] "+s"(occ)',
             '[vref] "+v"(stRef)', '[vlo] "+v"(stLo)', '[vhi] "+v"(stHi)']
-    outs += [f'[t{i}] "=&v"(t{i})' for i in range(15)]
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(12)]
     ins = ['[wb] "s"(wbase)', '[tb] "s"(tbase)', '[live] "s"(live)', '[thr] "s"(thr)', '[window] "s"(window)']
     ins += [f'[o{a}] "v"(r.o.{a})' for a in AX] + [f'[i{a}] "v"(r.inv.{a})' for a in AX] + [f'[d{a}] "v"(r.d.{a})' for a in AX]
-    ins += ['[tm] "v"(r.tmax)']
+    ins += ['[tm] "s"(tmax)']
     ins += [f'[cu{a}] "v"(w.cU.{a})' for a in AX] + [f'[cd{a}] "v"(w.cD.{a})' for a in AX]
-    clob = [f'"s{i}"' for i in range(BASE, BASE + (68 if PREFETCH else 66))] + ['"vcc"', '"scc"', '"m0"']
+    clob = [f'"s{i}"' for i in range(BASE, BASE + NSGPR + (2 if PREFETCH else 0))] + ['"vcc"', '"scc"', '"m0"']
     return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
             f"{ind}    : {', '.join(clob)});\n")
 
@@ -309,17 +324,17 @@ def main():
          "// form 0..7: ordered slab tests for the sign octant (bit a set <=> 1/d component a negative in every lane); 8: generic.",
          "",
          "__device__ __forceinline__ uint32_t wideDescend(uint32_t form, const void* wbase, const void* tbase, const Ray& r,",
-         "                                              const WideRay& w, uint64_t live, uint64_t& occ, uint32_t& sp,",
+         "                                              const WideRay& w, float tmax, uint64_t live, uint64_t& occ, uint32_t& sp,",
          "                                              uint32_t& stRef, uint32_t& stLo, uint32_t& stHi, uint32_t window, uint32_t thr) {",
-         "    uint32_t st, acc = 0;",
+         "    uint32_t acc = 0;",
          "    int32_t budget = (int32_t)window - 1;",
-         "    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;",
+         "    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11;",
          "    switch (form) {"]
     for octant in range(9):
         o.append(f"    case {octant}:" if octant < 8 else "    default:")
         o.append(emit(octant, "        ").rstrip("\n"))
         o.append("        break;")
-    o += ["    }", "    return st;", "}", ""]
+    o += ["    }", "    return acc;", "}", ""]
     open(OUT, "w").write("\n".join(o))
     print("wrote", OUT, sum(1 for _ in open(OUT)), "lines")
 
