@@ -18,6 +18,8 @@
 //   step     slab + the scalar side of a down-step of the real loop: s_add, s_load_dwordx8 of a 32-byte node (always
 //            the same few nodes: scalar-cache hits), s_waitcnt, s_cmp, s_cbranch, s_andn2, s_cbranch (7 scalar)
 //   stepmiss step with the node address striding through a 64 MB table (scalar-cache and mostly L2 misses)
+//   pkfma    16 independent v_pk_fma_f32 (two fp32 FMAs per lane and instruction) on VGPR pairs   (round 3: could the wide
+//   pkfmas   the same with an SGPR pair as first source and the second one broadcast (op_sel)      node test be packed?)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -33,7 +35,7 @@
     "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t v_max_f32 %[t3], %[t3], %[t4]\n\t v_max3_f32 %[t3], %[t3], %[t5], 0\n\t"  \
     "v_cmp_ge_f32 s[54:55], %[t0], %[t3]\n\t"
 
-enum { FMA = 0, SLAB = 1, STEP = 2, STEPMISS = 3 };
+enum { FMA = 0, SLAB = 1, STEP = 2, STEPMISS = 3, PKFMA = 4, PKFMAS = 5 };
 
 template <int MODE>
 __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int iters, unsigned long long* stamps, float* sink) {
@@ -42,6 +44,9 @@ __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     float a[16];
     for (int k = 0; k < 16; ++k) a[k] = ox + k;
+    double b[16];                                         // (64-bit VGPR pairs for the packed forms)
+    for (int k = 0; k < 16; ++k) b[k] = (double)ox + k;
+    double ixy = (double)ix;
     unsigned long long members = ~0ull;
     unsigned off = (blockIdx.x * 2654435761u) & mask & ~31u;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -55,6 +60,21 @@ __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int
                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
                   "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
                 : "v"(ix));
+        } else if (MODE == PKFMA || MODE == PKFMAS) {
+#define PK(n) "v_pk_fma_f32 %" #n ", %" #n ", %16, %" #n "\n\t"
+#define PKS(n) "v_pk_fma_f32 %" #n ", s[40:41], %16, %" #n " op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+            if (MODE == PKFMA)
+                asm volatile(PK(0) PK(1) PK(2) PK(3) PK(4) PK(5) PK(6) PK(7) PK(8) PK(9) PK(10) PK(11) PK(12) PK(13) PK(14) PK(15)
+                             : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]),
+                               "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15])
+                             : "v"(ixy));
+            else
+                asm volatile("s_mov_b32 s40, 0x3f000000\n\t s_mov_b32 s41, 0x3f400000\n\t"
+                             PKS(0) PKS(1) PKS(2) PKS(3) PKS(4) PKS(5) PKS(6) PKS(7) PKS(8) PKS(9) PKS(10) PKS(11) PKS(12) PKS(13) PKS(14) PKS(15)
+                             : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]),
+                               "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15])
+                             : "v"(ixy)
+                             : "s40", "s41");
         } else if (MODE == SLAB) {
             asm volatile(SLAB16("o", "i")
                          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)
@@ -84,7 +104,7 @@ __global__ __launch_bounds__(64) void spin(const void* nodes, unsigned mask, int
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) { stamps[blockIdx.x * 3] = c1 - c0; stamps[blockIdx.x * 3 + 1] = r0; stamps[blockIdx.x * 3 + 2] = r1; }
     float s = t0 + t3 + (float)members;
-    for (int k = 0; k < 16; ++k) s += a[k];
+    for (int k = 0; k < 16; ++k) s += a[k] + (float)b[k];
     if (s == 123.456f) sink[0] = s;
 }
 
@@ -148,6 +168,8 @@ int main() {
     float* d_sink; hipMalloc(&d_sink, 64);
     printf("%s, %d CUs\n", prop.name, cus);
     for (int w : {1, 2, 4, 8}) run<FMA>("fma", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
+    for (int w : {1, 4, 8}) run<PKFMA>("pkfma", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
+    for (int w : {1, 4, 8}) run<PKFMAS>("pkfmas", w, 16, 2, d_nodes, 0, d_stamps, d_sink, cus);
     for (int w : {1, 2, 4, 8}) run<SLAB>("slab", w, 16, 0, d_nodes, 0, d_stamps, d_sink, cus);
     for (int w : {1, 2, 4, 8}) run<STEP>("step", w, 16, 9, d_nodes, 1023u, d_stamps, d_sink, cus);          // 1 KB of nodes: K$ hits
     for (int w : {4, 8}) run<STEPMISS>("stepmiss", w, 16, 9, d_nodes, (unsigned)(bytes - 1), d_stamps, d_sink, cus);
