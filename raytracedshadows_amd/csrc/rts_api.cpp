@@ -51,6 +51,7 @@ struct rts_ctx {
     // two-pass frames (option "tail"): one queue per stream that has traced with the option on
     struct TailQueue { void* stream; uint32_t* d_counts; void* d_entries; uint32_t cap; uint32_t frame; };
     std::vector<TailQueue> tailQueues;
+    int teamLook = 1, teamMinGive = 16;
     int teamTiles = 4;                       // option "team_tiles": tiles per wave a team owns
     int team = 0;                            // option "team": 0, or 2 / 4 / 8 waves per workgroup that help each other (stackless packet, one sample)
     int tail = 0;                            // option "tail": long waves of the first pass hand their rest to a tail pass
@@ -268,6 +269,8 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "team")) { if (value != 0 && value != 2 && value != 4 && value != 8) return RTS_ERR_INVALID_ARG; c->team = value; return RTS_OK; }
+    if (!strcmp(key, "team_look")) { if (value < 0 || value > 65535) return RTS_ERR_INVALID_ARG; c->teamLook = value; return RTS_OK; }
+    if (!strcmp(key, "team_min_give")) { if (value < 2 || value > 65) return RTS_ERR_INVALID_ARG; c->teamMinGive = value; return RTS_OK; }
     if (!strcmp(key, "team_tiles")) { if (value < 1 || value > 64) return RTS_ERR_INVALID_ARG; c->teamTiles = value; return RTS_OK; }
     if (!strcmp(key, "tail")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->tail = value; return RTS_OK; }   // 2: first pass only (timing; the mask is incomplete)
     if (!strcmp(key, "tail_windows")) { if (value < 0 || value > 0x1FFFF) return RTS_ERR_INVALID_ARG; c->tailWindows = value; return RTS_OK; }
@@ -426,6 +429,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (c->team && rts::teamSupported(variant, c->blockWaves, p)) {       // waves of a workgroup help each other (LDS hand-off)
         p.teamError = c->d_word + 8;
         p.teamTiles = (uint32_t)c->teamTiles;
+        p.teamLook = (uint32_t)c->teamLook; p.teamMinGive = (uint32_t)c->teamMinGive;
         c->lastKernel = c->team == 8 ? "shadowMaskTeamKernel<8>" : c->team == 4 ? "shadowMaskTeamKernel<4>" : "shadowMaskTeamKernel<2>";
         return hipStatus(rts::launchTeam(c->team, p, (hipStream_t)stream));
     }

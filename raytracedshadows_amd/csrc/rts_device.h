@@ -70,6 +70,7 @@ struct TraceParams {
     uint32_t tailIters;       // lane-per-ray iterations a dissolved packet of the first pass may use
     uint32_t tailSlicesLog2;
     uint32_t teamTiles;       // team kernel: tiles per wave a workgroup owns (its waves take them from a counter in LDS)
+    uint32_t teamLook, teamMinGive;   // team kernel: windows between two looks of a coherent packet at its siblings; walking lanes needed to hand pieces over
     uint32_t* teamError;      // team kernel: set when a wait ran into its watchdog (never seen; the mask is then not trustworthy)
     float offsets[64][4];
 };

@@ -218,8 +218,8 @@ template <int TEAM> struct TeamShared {
     uint32_t working;          // waves at work (own tile or a job) + jobs claimed but not yet taken up; 0 = everybody may leave
     uint32_t pieces[TEAM][13][64];         // ox oy oz dx dy dz ix iy iz tmax node bound owner, piece k in column k
 };
-static constexpr uint32_t TEAM_MIN_GIVE = 16;     // a wave hands pieces over when at least this many of its lanes walk
-static constexpr int32_t TEAM_LOOK = 1;           // a coherent packet looks for idle siblings every TEAM_LOOK + 1 windows
+// (TraceParams: teamMinGive = a wave hands pieces over when at least this many of its lanes walk; teamLook = a coherent packet
+//  looks for idle siblings every teamLook + 1 windows)
 
 template <int TEAM>
 __device__ __forceinline__ int teamFindIdle(TeamShared<TEAM>& t, uint32_t me) {
@@ -298,7 +298,7 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
                                               ShareDiag* diag = nullptr, const uint32_t* parents = nullptr, uint32_t bound0 = END,
                                               uint32_t cap = 0, const TailSink* sink = nullptr, uint32_t nodeCount = 0,
                                               TeamShared<(TEAM > 0 ? TEAM : 1)>* team = nullptr, uint32_t teamMe = 0, uint32_t teamTile = 0,
-                                              uint32_t owner0 = END, uint64_t occSeed = 0, uint64_t* occOut = nullptr) {
+                                              uint32_t owner0 = END, uint64_t occSeed = 0, uint64_t* occOut = nullptr, uint32_t teamMinGive = 16) {
     static_assert(!HALVE || (CONFIRM && !CAP), "a walk may only start in the middle of the stream when triangle hits are confirmed");
     uint32_t node = live ? start : END, bound = bound0, owner = TEAM > 0 && owner0 != END ? owner0 : laneId();
     if (HALVE) bound = bound < nodeCount ? bound : nodeCount;
@@ -327,7 +327,7 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
             // every fourth iteration (between two in-wave exchanges): is a wave of the workgroup idle?  Then the upper half
             // of the walking lanes hand their pieces over and are free for the in-wave sharing of the rest.
             const uint32_t nAct = (uint32_t)__builtin_popcountll(act);
-            if ((iter & 3u) == 2u && nAct >= TEAM_MIN_GIVE) {
+            if ((iter & 3u) == 2u && nAct >= teamMinGive) {
                 const int h = teamFindIdle(*team, teamMe);
                 if (h >= 0 && teamClaim(*team, h, teamTile)) {
                     const uint32_t lane = laneId();
@@ -618,7 +618,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     const uint32_t thr = p.packetBudget * p.packetShare;
     int32_t budget = (int32_t)window;
     // (TAIL) < 0: the packet was stopped by its budget; (TEAM) < 0: time for a look at the siblings
-    int32_t windowsLeft = TAIL ? (int32_t)(p.tailWindows & 0xFFFFu) : (TEAM > 0 ? TEAM_LOOK : 0);
+    int32_t windowsLeft = TAIL ? (int32_t)(p.tailWindows & 0xFFFFu) : (TEAM > 0 ? (int32_t)p.teamLook : 0);
     uint32_t acc = 0;
     bool leaf;
     do {
@@ -647,7 +647,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
             if constexpr (TEAM > 0) {
                 // a coherent packet comes back every few windows: it only dissolves (to hand rays to other waves) when a
                 // wave of the workgroup is idle; otherwise it walks on as a packet
-                if (windowsLeft < 0 && cur != END && teamFindIdle(*team, teamMe) < 0) { windowsLeft = TEAM_LOOK; leaf = true; continue; }
+                if (windowsLeft < 0 && cur != END && teamFindIdle(*team, teamMe) < 0) { windowsLeft = (int32_t)p.teamLook; leaf = true; continue; }
             }
             leaf = false;
         } else if constexpr (PREFETCH && K == 1)
@@ -704,7 +704,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                 result[k] = result[k] || h;
             } else if constexpr (TEAM > 0) {
                 const bool h = traverseShare<true, false, false, false, false, TEAM>(bvh, r[k], mine != END, mine, lds, shareDiag, nullptr, END, 0u,
-                                                                                     nullptr, 0u, team, teamMe, teamMe, END, occluded[k]);
+                                                                                     nullptr, 0u, team, teamMe, teamMe, END, occluded[k], nullptr, p.teamMinGive);
                 result[k] = result[k] || h;
             } else {
                 const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
@@ -1406,7 +1406,7 @@ void shadowMaskTeamKernel(TraceParams p) {
             uint64_t occ = 0;
             // (a job only ever comes from the FAST walk of a wave whose rays are all safe)
             traverseShare<true, false, false, false, false, TEAM>(bvh, r, mine, node, lds, nullptr, nullptr, bound, 0u, nullptr, 0u, &team, me, tile,
-                                                                  owner, seed, &occ);
+                                                                  owner, seed, &occ, p.teamMinGive);
             if (lane == 0) {
                 __hip_atomic_fetch_or(&team.hitsLo[tile], (uint32_t)occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_or(&team.hitsHi[tile], (uint32_t)(occ >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

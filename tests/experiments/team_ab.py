@@ -15,6 +15,8 @@ TEAMS = [int(v) for v in os.environ.get("TEAMS", "0,2,4,8").split(",")]
 N = int(os.environ.get("N", "100"))
 REPS = int(os.environ.get("REPS", "1"))
 TILES = [int(v) for v in os.environ.get("TILES", "4").split(",")]
+LOOKS = [int(v) for v in os.environ.get("LOOKS", "1").split(",")]
+GIVES = [int(v) for v in os.environ.get("GIVES", "16").split(",")]
 for cfg in sys.argv[1:] or ["atrium_1080p"]:
     wl = workloads.prepare_config(cfg, cache=True)
     W, H = wl.W, wl.H
@@ -25,9 +27,12 @@ for cfg in sys.argv[1:] or ["atrium_1080p"]:
         ctx.h2d(d_pos, wl.positions)
         ctx.set_option("kernel", 3)
         for rep in range(REPS):
-            for team, tiles in [(t, n) for t in TEAMS for n in (TILES if t else TILES[:1])]:
+            for team, tiles, look, give in [(t, n, l, g) for t in TEAMS for n in (TILES if t else TILES[:1]) for l in (LOOKS if t else LOOKS[:1])
+                                            for g in (GIVES if t else GIVES[:1])]:
                 ctx.set_option("team", team)
                 ctx.set_option("team_tiles", tiles)
+                ctx.set_option("team_look", look)
+                ctx.set_option("team_min_give", give)
                 ctx.h2d(d_m, np.full(W * H, 7, np.uint8))
                 ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_m, light=wl.light)      # first launch alone: a hang shows here
                 ctx.synchronize()
@@ -48,6 +53,6 @@ for cfg in sys.argv[1:] or ["atrium_1080p"]:
                 ctx.synchronize()
                 ctx.d2h(got, d_m)
                 bad2 = int(np.count_nonzero(got != expect.reshape(-1)))
-                print(f"{cfg} team {team} x {tiles} tiles: median {np.median(ts):.4f} ms, min {np.min(ts):.4f} = {wl.rays / np.median(ts) / 1e6:.1f} Grays/s; "
+                print(f"{cfg} team {team} x {tiles} tiles look {look} give {give}: median {np.median(ts):.4f} ms, min {np.min(ts):.4f} = {wl.rays / np.median(ts) / 1e6:.1f} Grays/s; "
                       f"{bad} / {bad2} bytes differ from the oracle (first / last launch); watchdog {ctx.get_option('team_error')} [{ctx.last_kernel_name()}]", flush=True)
         ctx.set_option("team", 0)
