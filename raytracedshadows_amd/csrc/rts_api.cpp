@@ -48,14 +48,6 @@ struct rts_ctx {
     int softSplit = 1;                       // option "soft_split": soft shadows with 4 waves per tile (samples side by side)
     uint32_t pixelBase = 0;                  // set around a host-pointer stripe (see rts_trace_shadow_mask)
     uint64_t* d_clockProbe = nullptr; size_t clockProbeRows = 0;    // option "clock_probe"
-    // two-pass frames (option "tail"): one queue per stream that has traced with the option on
-    struct TailQueue { void* stream; uint32_t* d_counts; void* d_entries; uint32_t cap; uint32_t frame; };
-    std::vector<TailQueue> tailQueues;
-    int teamLook = 1, teamMinGive = 16;
-    int teamTiles = 4;                       // option "team_tiles": tiles per wave a team owns
-    int team = 0;                            // option "team": 0, or 2 / 4 / 8 waves per workgroup that help each other (stackless packet, one sample)
-    int tail = 0;                            // option "tail": long waves of the first pass hand their rest to a tail pass
-    int tailWindows = 3, tailIters = 48, tailSlicesLog2 = 5, tailCap = 256, tailWaves = 8192;
 };
 
 namespace {
@@ -207,7 +199,6 @@ int rts_ctx_create(int device, rts_ctx** out) {
     hipError_t e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_word, 256);
-    if (e == hipSuccess) e = hipMemset(c->d_word, 0, 256);
     if (e != hipSuccess) { delete c; return hipStatus(e); }
     *out = c;
     return RTS_OK;
@@ -225,7 +216,6 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_word) (void)hipFree(c->d_word);
     if (c->d_clockProbe) (void)hipFree(c->d_clockProbe);
-    for (auto& q : c->tailQueues) { if (q.d_counts) (void)hipFree(q.d_counts); if (q.d_entries) (void)hipFree(q.d_entries); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -268,23 +258,6 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
         return RTS_OK;
     }
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
-    if (!strcmp(key, "team")) { if (value != 0 && value != 2 && value != 4 && value != 8) return RTS_ERR_INVALID_ARG; c->team = value; return RTS_OK; }
-    if (!strcmp(key, "team_look")) { if (value < 0 || value > 65535) return RTS_ERR_INVALID_ARG; c->teamLook = value; return RTS_OK; }
-    if (!strcmp(key, "team_min_give")) { if (value < 2 || value > 65) return RTS_ERR_INVALID_ARG; c->teamMinGive = value; return RTS_OK; }
-    if (!strcmp(key, "team_tiles")) { if (value < 1 || value > 64) return RTS_ERR_INVALID_ARG; c->teamTiles = value; return RTS_OK; }
-    if (!strcmp(key, "tail")) { if (value < 0 || value > 2) return RTS_ERR_INVALID_ARG; c->tail = value; return RTS_OK; }   // 2: first pass only (timing; the mask is incomplete)
-    if (!strcmp(key, "tail_windows")) { if (value < 0 || value > 0x1FFFF) return RTS_ERR_INVALID_ARG; c->tailWindows = value; return RTS_OK; }
-    if (!strcmp(key, "tail_iters")) { if (value < 0 || value > (1 << 24)) return RTS_ERR_INVALID_ARG; c->tailIters = value; return RTS_OK; }
-    if (!strcmp(key, "tail_slices")) { if (value < 0 || value > 6) return RTS_ERR_INVALID_ARG; c->tailSlicesLog2 = value; return RTS_OK; }   // log2
-    if (!strcmp(key, "tail_waves")) { if (value < 1 || value > (1 << 20)) return RTS_ERR_INVALID_ARG; c->tailWaves = value; return RTS_OK; }
-    if (!strcmp(key, "tail_cap")) {              // entries per shard (64 shards, 1 KB per entry); queues are re-made at the next trace
-        if (value < 1 || value > 16384) return RTS_ERR_INVALID_ARG;
-        RTS_HIP(hipSetDevice(c->device));
-        for (auto& q : c->tailQueues) { if (q.d_counts) RTS_HIP(hipFree(q.d_counts)); if (q.d_entries) RTS_HIP(hipFree(q.d_entries)); }
-        c->tailQueues.clear();
-        c->tailCap = value;
-        return RTS_OK;
-    }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "clock_probe")) {          // value = tile rows to stamp (0 = off); packet kernels on 2-D grids
         RTS_HIP(hipSetDevice(c->device));
@@ -324,33 +297,6 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "wide_copy")) { *value = c->wideCopy; return RTS_OK; }
     if (!strcmp(key, "builder_scratch")) { *value = (int)(c->scratchBytes >> 20); return RTS_OK; }     // MiB held
     if (!strcmp(key, "wide_lane")) { *value = c->wideLane; return RTS_OK; }
-    if (!strcmp(key, "team")) { *value = c->team; return RTS_OK; }
-    if (!strcmp(key, "team_tiles")) { *value = c->teamTiles; return RTS_OK; }
-    if (!strcmp(key, "team_error")) {            // diagnostics: a team kernel's wait ran into its watchdog (0 = never)
-        RTS_HIP(hipSetDevice(c->device));
-        uint32_t w = 0;
-        RTS_HIP(hipMemcpy(&w, c->d_word + 8, 4, hipMemcpyDeviceToHost));
-        *value = (int)w;
-        return RTS_OK;
-    }
-    if (!strcmp(key, "tail")) { *value = c->tail; return RTS_OK; }
-    if (!strcmp(key, "tail_windows")) { *value = c->tailWindows; return RTS_OK; }
-    if (!strcmp(key, "tail_iters")) { *value = c->tailIters; return RTS_OK; }
-    if (!strcmp(key, "tail_slices")) { *value = c->tailSlicesLog2; return RTS_OK; }
-    if (!strcmp(key, "tail_waves")) { *value = c->tailWaves; return RTS_OK; }
-    if (!strcmp(key, "tail_cap")) { *value = c->tailCap; return RTS_OK; }
-    if (!strcmp(key, "tail_entries")) {          // diagnostics: entries the last two-pass frame on the default stream queued
-        *value = 0;
-        RTS_HIP(hipSetDevice(c->device));
-        for (auto& q : c->tailQueues) {
-            if (q.stream != nullptr || q.frame == 0) continue;
-            uint32_t counts[64];
-            RTS_HIP(hipDeviceSynchronize());
-            RTS_HIP(hipMemcpy(counts, q.d_counts + ((q.frame - 1) % 3) * 64, sizeof(counts), hipMemcpyDeviceToHost));
-            for (uint32_t n : counts) *value += (int)(n < q.cap ? n : q.cap);
-        }
-        return RTS_OK;
-    }
     if (!strcmp(key, "soft_split")) { *value = c->softSplit; return RTS_OK; }
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
     if (!strcmp(key, "wide_levels")) { *value = (int)c->wideLevels; return RTS_OK; }
@@ -426,44 +372,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     }
     c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
-    if (c->team && rts::teamSupported(variant, c->blockWaves, p)) {       // waves of a workgroup help each other (LDS hand-off)
-        p.teamError = c->d_word + 8;
-        p.teamTiles = (uint32_t)c->teamTiles;
-        p.teamLook = (uint32_t)c->teamLook; p.teamMinGive = (uint32_t)c->teamMinGive;
-        c->lastKernel = c->team == 8 ? "shadowMaskTeamKernel<8>" : c->team == 4 ? "shadowMaskTeamKernel<4>" : "shadowMaskTeamKernel<2>";
-        return hipStatus(rts::launchTeam(c->team, p, (hipStream_t)stream));
-    }
-    // two-pass frame: the first pass stops its long waves at a budget, the tail pass finishes them with many waves per tile
-    rts_ctx::TailQueue* tq = nullptr;
-    if (c->tail && rts::tailSupported(variant, c->blockWaves, p)) {
-        for (auto& q : c->tailQueues) if (q.stream == stream) tq = &q;
-        if (!tq && c->tailQueues.size() < 16) {
-            rts_ctx::TailQueue q{ stream, nullptr, nullptr, (uint32_t)c->tailCap, 0 };
-            hipError_t e = hipMalloc((void**)&q.d_counts, 3 * 64 * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemset(q.d_counts, 0, 3 * 64 * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMalloc(&q.d_entries, (size_t)64 * q.cap * 1024);
-            if (e == hipSuccess) {
-                try { c->tailQueues.push_back(q); tq = &c->tailQueues.back(); } catch (...) { e = hipErrorOutOfMemory; }
-            }
-            if (e != hipSuccess) {             // no queue: the frame is traced in one pass
-                (void)hipGetLastError();
-                if (q.d_counts) (void)hipFree(q.d_counts);
-                if (q.d_entries) (void)hipFree(q.d_entries);
-                tq = nullptr;
-            }
-        }
-    }
-    if (tq) {
-        p.tailCounts = tq->d_counts; p.tailQueue = (uint4*)tq->d_entries; p.tailCap = tq->cap; p.tailSet = tq->frame % 3;
-        p.tailWindows = (uint32_t)c->tailWindows; p.tailIters = (uint32_t)c->tailIters; p.tailSlicesLog2 = (uint32_t)c->tailSlicesLog2;
-        ++tq->frame;
-        c->lastKernel = "shadowMaskPacketKernel<1>+tail";
-    }
-    hipError_t le = rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, (uint32_t)c->ldsPad);
-    if (le == hipSuccess && tq && c->tail != 2) le = rts::launchTail(p, (hipStream_t)stream, (uint32_t)c->tailWaves);
-    else if (le == hipSuccess && tq)          // (first pass alone: what the tail pass would have cleared)
-        le = hipMemsetAsync(tq->d_counts + ((p.tailSet + 1u) % 3u) * 64u, 0, 64 * sizeof(uint32_t), (hipStream_t)stream);
-    return hipStatus(le);
+    return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, (uint32_t)c->ldsPad));
 }
 
 int rts_trace_shadow_mask_device(rts_ctx* c, const rts_constants* k, const rts_light* light,

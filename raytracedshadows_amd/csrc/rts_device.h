@@ -60,18 +60,6 @@ struct TraceParams {
     uint32_t wideBytes;       // size of the private copy (wide nodes + triangle records, one allocation)
     uint32_t trisOffset;      // byte offset of the triangle records in it (tris == wide + trisOffset)
     uint32_t wideLane;        // dissolved wide packets continue lane per ray over the WIDE nodes (0: over the stream, stackless)
-    // two-pass frame (option "tail"): a wave of the first pass that has used up its budget writes the unfinished
-    // pieces of its rays into a queue entry; the tail pass walks every entry with `1 << tailSlicesLog2` waves side by side
-    uint32_t* tailCounts;     // 3 x 64 entry counters (64 shards; the three sets rotate from frame to frame), or NULL = one pass
-    uint4* tailQueue;         // 64 shards x tailCap entries x 64 lanes {node, bound, owner lane, tile x | tile y << 16}
-    uint32_t tailCap;         // entries per shard
-    uint32_t tailSet;         // counter set of this frame (0..2); the tail pass clears set (tailSet + 1) % 3
-    uint32_t tailWindows;     // coherence windows a packet of the first pass may use
-    uint32_t tailIters;       // lane-per-ray iterations a dissolved packet of the first pass may use
-    uint32_t tailSlicesLog2;
-    uint32_t teamTiles;       // team kernel: tiles per wave a workgroup owns (its waves take them from a counter in LDS)
-    uint32_t teamLook, teamMinGive;   // team kernel: windows between two looks of a coherent packet at its siblings; walking lanes needed to hand pieces over
-    uint32_t* teamError;      // team kernel: set when a wait ran into its watchdog (never seen; the mask is then not trustworthy)
     float offsets[64][4];
 };
 
@@ -79,9 +67,5 @@ const char* kernelName(int variant, bool mask);
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH);   // pixels covered by one block
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad = 0);
 hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream);
-bool tailSupported(int variant, int wavesPerBlock, const TraceParams& p);   // is there a first-pass instantiation for this launch?
-hipError_t launchTail(const TraceParams& p, hipStream_t stream, uint32_t waves);
-bool teamSupported(int variant, int wavesPerBlock, const TraceParams& p);   // option "team": waves of a workgroup help each other
-hipError_t launchTeam(int team, const TraceParams& p, hipStream_t stream);
 
 } // namespace rts

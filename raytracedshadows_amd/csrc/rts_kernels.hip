@@ -196,113 +196,15 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
     uint64_t tDissolve = 0;     // clock when the (last) packet of this wave dissolved
 };
 
-// ------------------------------------------------------------------------------------------------
-// TEAM sharing (kernel shadowMaskTeamKernel, option "team"): the waves of a workgroup help each other.
-//
-// A frame's time is bounded below by its longest wave: a tile whose rays graze geometry for hundreds of dependent node
-// fetches, long after the machine has run empty.  In-wave work sharing (below) spreads one ray over idle LANES, but such a
-// tile has no idle lanes.  Here a workgroup is TEAM waves whose tiles lie far apart in the image (long tiles come in
-// clusters); a wave that has finished its own tile posts itself as idle in LDS, and a wave whose lanes are all busy hands
-// HALF of its pieces -- ray, [node, bound), owner lane -- to an idle sibling through LDS.  The helper walks them like its own
-// (sharing in-wave, handing on to further idle siblings), ORs the owner lanes it found occluded into the owner tile's hit
-// mask and counts the job down; the owner waits for its jobs before it stores its bytes.  Any-hit is an OR over disjoint
-// pieces of the reference's walk, so the mask cannot change.  All traffic is LDS (about 100 ns per round trip; the
-// hand-off through device memory of round 3 cost 15-25 us per hop).
-// ------------------------------------------------------------------------------------------------
-template <int TEAM> struct TeamShared {
-    uint32_t state[TEAM];      // mailbox of wave w: 0 busy, 1 idle (waiting for a job), 2 claimed by a giver, 3 job posted
-    uint32_t pending[TEAM];    // jobs other waves still hold for tile w
-    uint32_t jobOwner[TEAM];   // posted job: the wave whose tile the pieces belong to ...
-    uint32_t jobCount[TEAM];   // ... and how many pieces (in slots 0 .. count-1)
-    uint32_t hitsLo[TEAM], hitsHi[TEAM];   // owner lanes of tile w that helpers found occluded
-    uint32_t working;          // waves at work (own tile or a job) + jobs claimed but not yet taken up; 0 = everybody may leave
-    uint32_t pieces[TEAM][13][64];         // ox oy oz dx dy dz ix iy iz tmax node bound owner, piece k in column k
-};
-// (TraceParams: teamMinGive = a wave hands pieces over when at least this many of its lanes walk; teamLook = a coherent packet
-//  looks for idle siblings every teamLook + 1 windows)
-
-template <int TEAM>
-__device__ __forceinline__ int teamFindIdle(TeamShared<TEAM>& t, uint32_t me) {
-    int found = -1;
-#pragma unroll
-    for (int w = TEAM - 1; w >= 0; --w) {
-        const uint32_t st = __hip_atomic_load(&t.state[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((uint32_t)w != me && st == 1u) found = w;
-    }
-    return __builtin_amdgcn_readfirstlane(found);
-}
-// claims idle wave h for a job on tile `tile` (false: somebody else was faster)
-template <int TEAM>
-__device__ __forceinline__ bool teamClaim(TeamShared<TEAM>& t, int h, uint32_t tile) {
-    uint32_t ok = 0;
-    if (laneId() == 0) {
-        uint32_t expected = 1u;
-        ok = __hip_atomic_compare_exchange_strong(&t.state[h], &expected, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-        if (ok) {
-            __hip_atomic_fetch_add(&t.working, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&t.pending[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
-}
-template <int TEAM>
-__device__ __forceinline__ void teamPost(TeamShared<TEAM>& t, int h, uint32_t count, uint32_t tile) {
-    if (laneId() == 0) { t.jobOwner[h] = tile; t.jobCount[h] = count; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (laneId() == 0) __hip_atomic_store(&t.state[h], 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// Two-pass frame (option "tail"): where a wave of the FIRST pass puts what it has not finished when its
-// budget is used up.  An entry is 64 x {node, bound, owner lane | tile x << 6, pixel row of the tile}: lane l's piece
-// [node, bound) of the ray of pixel `owner` of the tile (node == END: nothing).  64 shards with a counter each, so that
-// the waves of a frame do not meet on one address.
-struct TailSink {
-    uint32_t* counts;      // the 64 counters of this frame's set
-    uint4* queue;
-    uint32_t cap, shard, tileX, tileY;
-    // false: the shard is full -- the wave finishes its rays itself.  (Called in wave-uniform control flow.)
-    __device__ __forceinline__ bool reserve(uint4** entry) const {
-        uint32_t slot = 0;
-        if (laneId() == 0) slot = __hip_atomic_fetch_add(counts + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-        if (slot >= cap) return false;
-        *entry = queue + ((size_t)shard * cap + slot) * 64u;
-        return true;
-    }
-    __device__ __forceinline__ void put(uint4* entry, uint32_t node, uint32_t bound, uint32_t owner) const {
-        entry[laneId()] = uint4{ node, bound, owner | (tileX << 6), tileY };
-    }
-};
-
 // CONFIRM (rays handed over by the wide packet walk, which culls with a conservative test): such a ray can stand inside a
 // subtree whose root box it does not hit by the exact test, and reach a leaf there through a miss link.  A triangle hit
 // then only counts if the ray hits the box of the leaf's PARENT by the exact test -- by the enclosure property that is
 // "the reference's walk reaches this leaf" (rts_wide.hip).  The parent's index comes from the private parent table.
-// CAP (first pass of a two-pass frame): after `cap` iterations the pieces still being walked go to the tail queue and the
-// walk ends; rays found occluded so far are reported, the others stay "lit" until the tail pass says otherwise.
-// bound0: where this lane's walk ends (the tail pass walks slices of the index range).
-// HALVE (the tail pass; needs CONFIRM): a busy lane gives away the upper HALF of the index range it still has to cover,
-// [node + (bound - node) / 2, bound), instead of "everything after the subtree I stand in" -- with confirmed hits a walk may
-// start on any node (see shadowMaskTailKernel), so the cut needs no miss link, the two parts are of equal size in the
-// stream, and the exchange runs in every iteration in which enough lanes are idle: a wave that starts with a few long
-// pieces has all 64 lanes at work after three or four iterations.  nodeCount: N, what `bound == END` stands for.
-// EAGER (the tail pass): the exchange runs in EVERY iteration in which enough lanes are idle, not in every fourth.  A lane that
-// descends from a node hands the node's right child to an idle lane in the very next iteration (the miss link of the left
-// child IS the right child), so a long walk fans out along the tree itself, one level per iteration.
-// TEAM > 0 (shadowMaskTeamKernel): a wave whose lanes are busy hands half of its pieces to an idle wave of its workgroup.
-// teamTile: the wave whose tile these rays belong to (`owner` = lane of a ray in THAT wave); occSeed / occOut: owner lanes
-// known to be occluded when the walk starts / when it ends.
-template <bool FAST, bool CONFIRM = false, bool CAP = false, bool HALVE = false, bool EAGER = false, int TEAM = 0>
+template <bool FAST, bool CONFIRM = false>
 __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
-                                              ShareDiag* diag = nullptr, const uint32_t* parents = nullptr, uint32_t bound0 = END,
-                                              uint32_t cap = 0, const TailSink* sink = nullptr, uint32_t nodeCount = 0,
-                                              TeamShared<(TEAM > 0 ? TEAM : 1)>* team = nullptr, uint32_t teamMe = 0, uint32_t teamTile = 0,
-                                              uint32_t owner0 = END, uint64_t occSeed = 0, uint64_t* occOut = nullptr, uint32_t teamMinGive = 16) {
-    static_assert(!HALVE || (CONFIRM && !CAP), "a walk may only start in the middle of the stream when triangle hits are confirmed");
-    uint32_t node = live ? start : END, bound = bound0, owner = TEAM > 0 && owner0 != END ? owner0 : laneId();
-    if (HALVE) bound = bound < nodeCount ? bound : nodeCount;
-    uint64_t occludedOwners = TEAM > 0 ? occSeed : 0;  // wave-uniform
+                                              ShareDiag* diag = nullptr, const uint32_t* parents = nullptr) {
+    uint32_t node = live ? start : END, bound = END, owner = laneId();
+    uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
     // The loop is rotated: the node of the NEXT iteration is requested before the triangle of this one is tested.
     // A leaf's successor is known without any arithmetic (its miss link), and the triangle's v0 is a load that
@@ -317,44 +219,11 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
     for (;;) {
         const uint64_t act = __builtin_amdgcn_ballot_w64(active);
         if (act == 0) break;
-        if (CAP && iter >= cap) {                                    // budget used up: hand the pieces to the tail pass
-            uint4* entry;
-            if (sink->reserve(&entry)) { sink->put(entry, active ? node : END, bound, owner); break; }
-            cap = END;                                               // queue full: finish here
-        }
         if (diag && diag->on) { diag->iterations += 1u; diag->laneSteps += (uint32_t)__builtin_popcountll(act); }
-        if constexpr (TEAM > 0) {
-            // every fourth iteration (between two in-wave exchanges): is a wave of the workgroup idle?  Then the upper half
-            // of the walking lanes hand their pieces over and are free for the in-wave sharing of the rest.
-            const uint32_t nAct = (uint32_t)__builtin_popcountll(act);
-            if ((iter & 3u) == 2u && nAct >= teamMinGive) {
-                const int h = teamFindIdle(*team, teamMe);
-                if (h >= 0 && teamClaim(*team, h, teamTile)) {
-                    const uint32_t lane = laneId();
-                    const uint32_t below = (1u << (lane & 31u)) - 1u;
-                    const uint32_t rank = lane < 32 ? __builtin_popcount((uint32_t)act & below)
-                                                    : __builtin_popcount((uint32_t)act) + __builtin_popcount((uint32_t)(act >> 32) & below);
-                    const uint32_t keep = nAct - (nAct >> 1);
-                    const bool gives = active && rank >= keep;
-                    if (gives) {
-                        uint32_t (*pc)[64] = team->pieces[h];
-                        const uint32_t k = rank - keep;
-                        pc[0][k] = __float_as_uint(r.o.x); pc[1][k] = __float_as_uint(r.o.y); pc[2][k] = __float_as_uint(r.o.z);
-                        pc[3][k] = __float_as_uint(r.d.x); pc[4][k] = __float_as_uint(r.d.y); pc[5][k] = __float_as_uint(r.d.z);
-                        pc[6][k] = __float_as_uint(r.inv.x); pc[7][k] = __float_as_uint(r.inv.y); pc[8][k] = __float_as_uint(r.inv.z);
-                        pc[9][k] = __float_as_uint(r.tmax); pc[10][k] = node; pc[11][k] = bound; pc[12][k] = owner;
-                        bound = 0; active = false;                   // this lane has nothing left (and is idle for the in-wave sharing)
-                    }
-                    teamPost(*team, h, nAct >> 1, teamTile);
-                }
-            }
-        }
         uint32_t next = node;                                        // lanes that do not move keep their (finished) range
-        if (HALVE || EAGER || (iter++ & 3u) == 0) {
-            const uint64_t idle = TEAM > 0 ? ~__builtin_amdgcn_ballot_w64(active) : ~act;
-            // the part to give away starts at `cut`: the miss link of the node the lane stands on, or the middle of its range
-            const uint32_t cut = HALVE ? node + ((bound - node) >> 1) : b.w;
-            const bool canGive = active && (HALVE ? bound - node >= 16u : b.w < bound);
+        if ((iter++ & 3u) == 0) {
+            const uint64_t idle = ~act;
+            const bool canGive = active && b.w < bound;              // there is a second part to give away
             const uint64_t givers = __builtin_amdgcn_ballot_w64(canGive);
             const uint32_t nIdle = (uint32_t)__builtin_popcountll(idle), nGive = (uint32_t)__builtin_popcountll(givers);
             if (nIdle >= SHARE_MIN_IDLE && nGive != 0) {
@@ -383,14 +252,14 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
                 const float iy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.inv.y)));
                 const float iz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.inv.z)));
                 const float tm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, r.tmax)));
-                const uint32_t srcNext = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)cut);
+                const uint32_t srcNext = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)b.w);
                 const uint32_t srcBound = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)bound);
                 const uint32_t srcOwner = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)owner);
                 if (takes) {
                     r.o = F3{ ox, oy, oz }; r.d = F3{ dx, dy, dz }; r.inv = F3{ ix, iy, iz }; r.tmax = tm;
                     next = srcNext; bound = srcBound; owner = srcOwner;   // its first node is requested below
                 }
-                if (gives) bound = cut;                              // keeps [node, cut)
+                if (gives) bound = b.w;                              // keeps [node, next(node))
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -426,7 +295,6 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
         // pieces of an owner that is known to be occluded have nothing left to prove
         active = nextActive && !((occludedOwners >> owner) & 1ull);
     }
-    if (TEAM > 0 && occOut) *occOut = occludedOwners;
     return (occludedOwners >> laneId()) & 1ull;
 }
 
@@ -557,14 +425,10 @@ __device__ __forceinline__ uint32_t waveMinU32(uint32_t v) {
 // (v_min/v_max per axis) runs, and waves with an unsafe ray go lane-per-ray with the EXACT form.
 #include "rts_packet_asm.inc"
 
-template <int K, bool PREFETCH = false, bool TAIL = false, int TEAM = 0>
+template <int K, bool PREFETCH = false>
 __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeStream& bvh, const Ray (&r)[K],
                                                const bool (&live)[K], bool (&result)[K], uint32_t* lds,
-                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr,
-                                               const TailSink* sink = nullptr, TeamShared<(TEAM > 0 ? TEAM : 1)>* team = nullptr,
-                                               uint32_t teamMe = 0) {
-    static_assert(!TAIL || (K == 1 && !PREFETCH), "the first pass of a two-pass frame exists for the one-tile packet only");
-    static_assert(TEAM == 0 || (K == 1 && !PREFETCH && !TAIL), "team sharing exists for the one-tile packet only");
+                                               int32_t* sideStepsLeft = nullptr, ShareDiag* shareDiag = nullptr) {
     // (the stream's address as an explicitly wave-uniform value: when this function is inlined into a loop over tiles the
     //  compiler may keep the kernel argument in VGPRs, which the asm's scalar loads cannot take)
     const uint64_t bvhAddr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)p.bvh >> 32)) << 32) |
@@ -587,7 +451,7 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     if (any == 0) return;
     if (!p.bvhFinite || unsafe != 0) {       // a NaN could occur somewhere in this wave: EXACT form, lane per ray
 #pragma unroll
-        for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], 0u, lds);   // (never handed to other waves: they walk with the FAST form)
+        for (int k = 0; k < K; ++k) result[k] = traverseShare<false>(bvh, r[k], live[k], 0u, lds);
         return;
     }
     // sign pattern of 1/d over all live rays of the wave: uniform -> ordered slab test.  (1/d is finite and non-zero for
@@ -617,14 +481,11 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
     const uint32_t window = p.packetBudget - 1u;
     const uint32_t thr = p.packetBudget * p.packetShare;
     int32_t budget = (int32_t)window;
-    // (TAIL) < 0: the packet was stopped by its budget; (TEAM) < 0: time for a look at the siblings
-    int32_t windowsLeft = TAIL ? (int32_t)(p.tailWindows & 0xFFFFu) : (TEAM > 0 ? (int32_t)p.teamLook : 0);
     uint32_t acc = 0;
     bool leaf;
     do {
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
         budget = __builtin_amdgcn_readfirstlane(budget);
-        if constexpr (TAIL || TEAM > 0) windowsLeft = __builtin_amdgcn_readfirstlane(windowsLeft);
         acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -635,19 +496,12 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)occluded[0]);
             // leaves are handled inside the asm loop; it only comes back when the packet is finished (cur == END),
             // dissolves, or (code 2) stands on a node nobody waits on after all its rays got occluded
-            uint32_t code;
-            if constexpr (TAIL || TEAM > 0) code = packetDescendLeafDeadline(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window, windowsLeft);
-            else code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window);
+            const uint32_t code = packetDescendLeaf(form, bvhBase, r, cur, members, wait, occluded, budget, acc, thr, window);
             if (code == 2) {
                 cur = waveMinU32(wait[0]);
                 members[0] = __builtin_amdgcn_ballot_w64(wait[0] == cur);
                 leaf = true;                         // (keeps the loop going; the leaf block below is skipped)
                 continue;
-            }
-            if constexpr (TEAM > 0) {
-                // a coherent packet comes back every few windows: it only dissolves (to hand rays to other waves) when a
-                // wave of the workgroup is idle; otherwise it walks on as a packet
-                if (windowsLeft < 0 && cur != END && teamFindIdle(*team, teamMe) < 0) { windowsLeft = (int32_t)p.teamLook; leaf = true; continue; }
             }
             leaf = false;
         } else if constexpr (PREFETCH && K == 1)
@@ -694,22 +548,8 @@ __device__ __forceinline__ void traversePacket(const TraceParams& p, const NodeS
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t mine = __builtin_amdgcn_inverse_ballot_w64(members[k]) ? cur : wait[k];
-            if constexpr (TAIL) {
-                // a packet stopped by its budget goes to the tail pass as it stands; one that dissolved on its own walks
-                // on lane per ray, with a budget of iterations
-                uint4* entry;
-                if (windowsLeft < 0 && sink->reserve(&entry)) { sink->put(entry, mine, END, laneId()); continue; }
-                const bool h = traverseShare<true, false, true>(bvh, r[k], mine != END, mine, lds, shareDiag, nullptr, END,
-                                                                windowsLeft < 0 ? END : p.tailIters, sink);
-                result[k] = result[k] || h;
-            } else if constexpr (TEAM > 0) {
-                const bool h = traverseShare<true, false, false, false, false, TEAM>(bvh, r[k], mine != END, mine, lds, shareDiag, nullptr, END, 0u,
-                                                                                     nullptr, 0u, team, teamMe, teamMe, END, occluded[k], nullptr, p.teamMinGive);
-                result[k] = result[k] || h;
-            } else {
-                const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
-                result[k] = result[k] || h;
-            }
+            const bool h = traverseShare<true>(bvh, r[k], mine != END, mine, lds, shareDiag);
+            result[k] = result[k] || h;
         }
     }
 }
@@ -1188,11 +1028,7 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // BANDS (with PLAIN): the everyday launch of ONE STRIPE of a frame cut into interleaved bands (multi-GPU):
 // a band is 2^bandShift tile rows, so the frame row of a tile row is two shifts and a multiply on the scalar unit
 // instead of the general prologue with its per-lane division.
-// TAIL (with PLAIN, one sample): the FIRST pass of a two-pass frame.  A wave whose packet has used up `tailWindows` coherence
-// windows, or whose dissolved rays have walked `tailIters` iterations, writes what is left of its rays into the tail queue
-// and ends; shadowMaskTailKernel finishes them with many waves per tile.
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false,
-          bool TAIL = false>
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false>
 // (Registers: a SIMD holds 8 waves of a kernel only up to 64 VGPRs AND 80 SGPRs including VCC / FLAT_SCRATCH / XNACK: the
 //  next granule, 96, plus the 16 the trap handler adds per wave fits 800 only 7 times -- measured with the hardware slot ids
 //  of the probe waves, DESIGN.md 4.7.  Every K = 1 instantiation is inside both limits; tools/gen_wide_asm.py budgets for it.)
@@ -1200,7 +1036,6 @@ __global__ __launch_bounds__(64 * WPB * SPLIT) __attribute__((amdgpu_waves_per_e
 void shadowMaskPacketKernel(TraceParams p) {
     static_assert(!BANDS || (PLAIN && K == 1 && WPB == 1), "the band form exists for the one-tile everyday launch only");
     static_assert(SPLIT == 1 || (K == 1 && WPB == 1 && SOFT), "samples are split over waves in the one-tile soft-shadow form only");
-    static_assert(!TAIL || (PLAIN && K == 1 && WPB == 1 && !SOFT && SPLIT == 1), "the first pass of a two-pass frame is an everyday one-sample launch");
     __shared__ uint32_t shareSlots[WPB * SPLIT][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     // per-lane stacks of the wide lane walk: 4 KB per wave -- which caps a CU at 28 one-wave workgroups instead of 32, so
@@ -1218,7 +1053,6 @@ void shadowMaskPacketKernel(TraceParams p) {
     bool live[K];
     size_t pix[K];
     F3 rel[K];
-    uint32_t rowOfRay0 = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t x = x0 + (k & 1) * 8u;
@@ -1228,7 +1062,6 @@ void shadowMaskPacketKernel(TraceParams p) {
             y = (band * p.nStripes + p.stripe) * p.bandRows + within * 8u + (lane >> 3);
         } else y = PLAIN ? p.rowBegin + v0 + (k >> 1) * 8u : ownedRow(p, v0 + (k >> 1) * 8u);
         live[k] = (x < p.W) && (y < p.rowEnd);
-        if (k == 0) rowOfRay0 = y;
         pix[k] = (size_t)y * p.W + x;
         rel[k] = F3{ 0.f, 0.f, 0.f };
         if (live[k]) {
@@ -1262,14 +1095,8 @@ void shadowMaskPacketKernel(TraceParams p) {
             asm volatile("" :: "v"(r[0].inv.x), "v"(r[0].inv.y), "v"(r[0].inv.z), "v"(r[0].o.x));
             tReady = __builtin_amdgcn_s_memtime();
         }
-        TailSink sink;
-        if constexpr (TAIL) {
-            sink.counts = p.tailCounts + p.tailSet * 64u; sink.queue = p.tailQueue; sink.cap = p.tailCap;
-            sink.shard = (bx + by) & 63u; sink.tileX = bx;
-            sink.tileY = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowOfRay0);          // lane 0: the tile's first pixel row
-        }
         if constexpr (WIDE != 0) occluded[0] = traverseWide<WIDE != 2>(p, bvh, r[0], live[0], lds, laneStack, &left, &shareDiag);
-        else traversePacket<K, PREFETCH, TAIL>(p, bvh, r, live, occluded, lds, &left, &shareDiag, TAIL ? &sink : nullptr);
+        else traversePacket<K, PREFETCH>(p, bvh, r, live, occluded, lds, &left, &shareDiag);
 #pragma unroll
         for (int k = 0; k < K; ++k) lit[k] += occluded[k] ? 0u : 1u;                     // comp:148
     }
@@ -1314,163 +1141,6 @@ void shadowMaskPacketKernel(TraceParams p) {
         o[2] = (left < 0 ? 1ull : 0ull) | ((uint64_t)(shareDiag.iterations & 0xFFFFFFu) << 8) |
                ((shareDiag.tDissolve ? (shareDiag.tDissolve - tStart) & 0xFFFFFFFFull : 0ull) << 32);
         o[3] = ((uint64_t)bx << 48) | ((uint64_t)(by & 0xFFFFu) << 32) | shareDiag.laneSteps;   // ... and the lane-steps in them
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// shadowMaskTeamKernel: the everyday one-sample launch of the stackless packet with TEAM waves per workgroup that help each
-// other (see "TEAM sharing" above).  A workgroup owns TEAM * teamTiles tiles -- tile g + j * (number of workgroups) for
-// j = 0, 1, ...: far apart in the image, because long tiles come in clusters -- and its waves take them one after the other
-// from a counter in LDS.  A wave that finds the list empty posts itself as idle and helps whoever is still walking; so the
-// waves of a team finish together, and a tile that would have been one wave's 130 us is four waves' 40.
-// ------------------------------------------------------------------------------------------------
-template <int TEAM>
-__global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(8)))
-void shadowMaskTeamKernel(TraceParams p) {
-    __shared__ TeamShared<TEAM> team;
-    __shared__ uint32_t shareSlots[TEAM][64];
-    __shared__ uint32_t nextTile;
-    const uint32_t lane = threadIdx.x & 63u, me = threadIdx.x >> 6;
-    uint32_t* lds = shareSlots[me];
-    if (lane == 0) { team.state[me] = 0u; team.pending[me] = 0u; team.hitsLo[me] = 0u; team.hitsHi[me] = 0u; }
-    if (threadIdx.x == 0) { team.working = (uint32_t)TEAM; nextTile = 0u; }
-    __syncthreads();
-    const NodeStream bvh = openStream(p);
-    const uint32_t listed = (uint32_t)TEAM * p.teamTiles;
-    for (;;) {
-        uint32_t j = 0;
-        if (lane == 0) j = __hip_atomic_fetch_add(&nextTile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-        const uint32_t t = blockIdx.x + j * gridDim.x;                // (nBlocks < 2^31 / 64: no overflow for j < listed)
-        if (j >= listed || t >= p.nBlocks) break;
-        const uint32_t by = t / p.blocksX, bx = t - by * p.blocksX;
-        const uint32_t x = bx * 8u + (lane & 7u);
-        uint32_t y = p.rowBegin + by * 8u + (lane >> 3);
-        if (p.nStripes > 1u) {                                        // one stripe of a frame cut into interleaved bands of 2^bandShift tile rows
-            const uint32_t band = by >> p.bandShift, within = by - (band << p.bandShift);
-            y = (band * p.nStripes + p.stripe) * p.bandRows + within * 8u + (lane >> 3);
-        }
-        const bool live[1] = { (x < p.W) && (y < p.rowEnd) };
-        const size_t pix = (size_t)y * p.W + x;
-        F3 rel{ 0.f, 0.f, 0.f };
-        if (live[0]) { const f32x4 tx = __builtin_nontemporal_load((const f32x4*)p.positions + pix); rel = F3{ tx.x, tx.y, tx.z }; }   // comp:135
-        const bool probe = p.clockProbe != nullptr && bx == 0 && lane == 0;
-        if (probe) { uint64_t* o = p.clockProbe + (size_t)by * 4; o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime(); }
-        const Ray r[1] = { makeShadowRay(p, rel, 0u, (uint32_t)pix) };
-        bool occluded[1];
-        traversePacket<1, false, false, TEAM>(p, bvh, r, live, occluded, lds, nullptr, nullptr, nullptr, &team, me);
-        // the jobs other waves hold for this tile: wait for them, then their hits count too
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&team.pending[me], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 24)) { if (lane == 0 && p.teamError) *p.teamError = 1u; break; }      // (never seen: a wedged workgroup must not hang the device)
-        }
-        const uint64_t helped = ((uint64_t)__hip_atomic_load(&team.hitsHi[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32) |
-                                __hip_atomic_load(&team.hitsLo[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool occ = occluded[0] || ((helped >> lane) & 1ull);
-        if (live[0]) __builtin_nontemporal_store((uint8_t)(occ ? 0u : 1u), &p.mask[pix]);    // comp:148-150
-        if (lane == 0) { team.hitsLo[me] = 0u; team.hitsHi[me] = 0u; }                       // (nobody holds a job for this tile any more)
-        if (probe) {
-            uint64_t* o = p.clockProbe + (size_t)by * 4;
-            uint32_t hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            o[1] = (__builtin_amdgcn_s_memtime() & 0x0000FFFFFFFFFFFFull) | ((uint64_t)(hwid & 0xFFFFu) << 48);
-            o[3] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-    // the list is empty: take jobs until nobody in the workgroup works any more
-    if (lane == 0) {
-        __hip_atomic_fetch_sub(&team.working, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&team.state[me], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    uint32_t spins = 0;
-    for (;;) {
-        const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&team.state[me], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (st == 3u) {
-            spins = 0;
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)team.jobCount[me]);
-            const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)team.jobOwner[me]);
-            uint32_t (*pc)[64] = team.pieces[me];
-            const bool mine = lane < n;
-            const uint32_t k = mine ? lane : 0u;
-            Ray r;
-            r.o = F3{ __uint_as_float(pc[0][k]), __uint_as_float(pc[1][k]), __uint_as_float(pc[2][k]) };
-            r.d = F3{ __uint_as_float(pc[3][k]), __uint_as_float(pc[4][k]), __uint_as_float(pc[5][k]) };
-            r.inv = F3{ __uint_as_float(pc[6][k]), __uint_as_float(pc[7][k]), __uint_as_float(pc[8][k]) };
-            r.tmax = __uint_as_float(pc[9][k]);
-            const uint32_t node = pc[10][k], bound = pc[11][k], owner = pc[12][k];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) __hip_atomic_store(&team.state[me], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // busy; the pieces are in registers
-            const uint64_t seed = ((uint64_t)__hip_atomic_load(&team.hitsHi[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 32) |
-                                  __hip_atomic_load(&team.hitsLo[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            uint64_t occ = 0;
-            // (a job only ever comes from the FAST walk of a wave whose rays are all safe)
-            traverseShare<true, false, false, false, false, TEAM>(bvh, r, mine, node, lds, nullptr, nullptr, bound, 0u, nullptr, 0u, &team, me, tile,
-                                                                  owner, seed, &occ, p.teamMinGive);
-            if (lane == 0) {
-                __hip_atomic_fetch_or(&team.hitsLo[tile], (uint32_t)occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_or(&team.hitsHi[tile], (uint32_t)(occ >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_sub(&team.pending[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_sub(&team.working, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&team.state[me], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            continue;
-        }
-        if (st == 1u && (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&team.working, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { if (lane == 0 && p.teamError) *p.teamError = 2u; break; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The TAIL pass of a two-pass frame (option "tail").
-//
-// A frame's time is bounded below by its longest wave, and the longest waves are tiles whose rays graze geometry for
-// hundreds of dependent node fetches while the rest of the machine has long run empty.  The first pass therefore stops such
-// a wave after a budget and leaves an entry in the tail queue: per lane one piece [node, bound) of the stackless walk of
-// one of the tile's rays.  Here every entry is taken up by 1 << tailSlicesLog2 waves; each starts with its share of the
-// entry's pieces in its first lanes and spreads them over all 64 by halving index ranges (traverseShare<.., HALVE>).
-//
-// Why any index interval may be walked on its own: a stackless walk that starts on ANY node s and runs while the index
-// stays below b visits exactly the nodes of [s, b) whose ancestors inside [s, b) it hits; the ancestors before s are not
-// tested.  By the enclosure property (rts_wide.hip; checked per stream on the device) the reference's walk reaches a leaf iff
-// the ray hits the box of the leaf's PARENT, so a triangle hit that is confirmed against that box (traverseShare<..,
-// CONFIRM>, the rule of the wide kernels) is a hit of the reference's walk, and no hit of the reference's walk is lost: its
-// leaf lies in exactly one interval and all of its ancestors are hit.  Any-hit is an OR over the intervals; the first pass
-// wrote 1 for every unfinished ray, this pass only ever writes 0.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void shadowMaskTailKernel(TraceParams p) {
-    __shared__ uint32_t shareSlots[64];
-    const uint32_t lane = threadIdx.x;
-    // the counters of the set after this frame's are cleared here: the next frame's first pass starts after this launch
-    if (blockIdx.x == 0) p.tailCounts[((p.tailSet + 1u) % 3u) * 64u + lane] = 0u;
-    uint32_t mine = p.tailCounts[p.tailSet * 64u + lane];            // entries in shard `lane` (a full shard counts on: clamp)
-    mine = mine < p.tailCap ? mine : p.tailCap;
-    uint32_t incl = mine;                                            // inclusive prefix sum over the shards
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
-    const uint32_t entries = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t gl = p.tailSlicesLog2, G = 64u >> gl;             // waves per entry = 1 << gl, pieces per wave = G
-    const uint32_t N = 2u * p.primCount - 1u;
-    const NodeStream bvh = openStream(p);
-    for (uint64_t item = blockIdx.x; item < ((uint64_t)entries << gl); item += gridDim.x) {
-        const uint32_t e = (uint32_t)(item >> gl), g = (uint32_t)item & ((1u << gl) - 1u);
-        const uint32_t sh = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(incl > e));     // the shard entry e lies in
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)sh) - (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)sh);
-        uint4 q{ END, END, 0u, 0u };
-        if (lane < G) q = p.tailQueue[((size_t)sh * p.tailCap + (e - first)) * 64u + g * G + lane];
-        const uint32_t end = q.y < N ? q.y : N;
-        const bool has = q.x < end;
-        if (__builtin_amdgcn_ballot_w64(has) == 0) continue;
-        const uint32_t owner = q.z & 63u;
-        const size_t pix = (size_t)(q.w + (owner >> 3)) * p.W + ((q.z >> 6) * 8u + (owner & 7u));
-        F3 rel{ 0.f, 0.f, 0.f };
-        if (has) { const f32x4 t = *((const f32x4*)p.positions + pix); rel = F3{ t.x, t.y, t.z }; }
-        const Ray r = makeShadowRay(p, rel, 0u, (uint32_t)pix);
-        bool h;
-        if (p.tailWindows & 0x10000u) h = traverseShare<true, true, false, true>(bvh, r, has, q.x, shareSlots, nullptr, p.parents, end, 0u, nullptr, N);
-        else h = traverseShare<true, false, false, false, true>(bvh, r, has, q.x, shareSlots, nullptr, nullptr, end);
-        if (h) p.mask[pix] = 0;
     }
 }
 
@@ -1570,8 +1240,6 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
             else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true>), grid, b1, ldsPad, stream, p);
-            else if (p.tailCounts && tailSupported(variant, wavesPerBlock, p))
-                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, false, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true>), grid, b1, ldsPad, stream, p);
             else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false>), grid, b1, ldsPad, stream, p);
@@ -1594,33 +1262,6 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     case V_PACKET_PF: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, false>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-
-// The first pass exists for the everyday one-sample launch of the one-tile stackless packet over a stream with the
-// enclosure property (the tail pass confirms hits through the private parent table).
-bool tailSupported(int variant, int wavesPerBlock, const TraceParams& p) {
-    return variant == V_PACKET && wavesPerBlock == 1 && p.nsamples <= 1 && p.grid2d && p.nStripes <= 1 && !p.waveStats &&
-           p.parents != nullptr && p.bvhFinite && p.bvhOrdered;
-}
-
-// Team launch: a 1-D grid of workgroups of `team` waves; workgroup g owns tiles g, g + G, g + 2G, ... (team * teamTiles of them).
-bool teamSupported(int variant, int wavesPerBlock, const TraceParams& p) {
-    return variant == V_PACKET && wavesPerBlock == 1 && p.nsamples <= 1 && p.grid2d && !p.waveStats && p.rowOrder == 0 &&
-           (p.nStripes <= 1 || p.bandShift != 0xFFFFFFFFu);
-}
-hipError_t launchTeam(int team, const TraceParams& p, hipStream_t stream) {
-    const uint32_t per = (uint32_t)team * (p.teamTiles ? p.teamTiles : 1u);
-    const dim3 grid((p.nBlocks + per - 1u) / per);
-    if (team == 8) hipLaunchKernelGGL(shadowMaskTeamKernel<8>, grid, dim3(512), 0, stream, p);
-    else if (team == 4) hipLaunchKernelGGL(shadowMaskTeamKernel<4>, grid, dim3(256), 0, stream, p);
-    else if (team == 2) hipLaunchKernelGGL(shadowMaskTeamKernel<2>, grid, dim3(128), 0, stream, p);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-hipError_t launchTail(const TraceParams& p, hipStream_t stream, uint32_t waves) {
-    hipLaunchKernelGGL(shadowMaskTailKernel, dim3(waves), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

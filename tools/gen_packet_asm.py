@@ -213,13 +213,8 @@ def loop_prefetch(form):
 
 
 
-def loop_leaf(form, deadline=False):
+def loop_leaf(form):
     """K = 1, leaves handled inside the loop (no exit to compiled code per leaf visit).
-
-    deadline: %[wl] counts the coherence windows after which the caller wants to look at the packet (is a
-    sibling wave idle? is the budget of the first pass used up?); when it runs out the loop is left through the dissolve
-    exit with wl = -1 and the window statistics reset, so the caller may simply come back.  Two scalar instructions per
-    window.
 
     Triangle test = RayTracedShadows.comp:41-59 operation for operation (separate mul/sub/add, no contraction;
     dot products left to right; 1/det with the correctly rounded divide sequence hipcc emits for `1.0f / x`).
@@ -253,22 +248,17 @@ def loop_leaf(form, deadline=False):
           "s_bcnt1_i32_b64 s50, %[m0]",
           "s_add_u32 %[acc], %[acc], s50",
           "s_sub_u32 %[budget], %[budget], 1",
-          "s_cbranch_scc0 2b"]
-    L += ["v_cmp_ne_u32 s[48:49], -1, %[w0]",
+          "s_cbranch_scc0 2b",
+          "v_cmp_ne_u32 s[48:49], -1, %[w0]",
           "s_or_b64 s[48:49], s[48:49], %[m0]",
           "s_bcnt1_i32_b64 s51, s[48:49]",
           "s_mul_i32 s51, s51, %[thr]",
           "s_lshl_b32 s50, %[acc], 4",
           "s_mov_b32 %[acc], 0",
           "s_mov_b32 %[budget], %[window]",
-          "s_cmp_lt_u32 s50, s51"]
-    if deadline:
-        L += ["s_cbranch_scc1 8f",                        # not coherent enough: dissolve (wl stays >= 0)
-              "s_sub_u32 %[wl], %[wl], 1",                # coherent: was this the last window before the caller wants a look?
-              "s_cbranch_scc0 2b"]                        # (falls through with wl = -1; acc and budget are already reset)
-    else:
-        L += ["s_cbranch_scc0 2b"]
-    L += ["8:",                                           # dissolve
+          "s_cmp_lt_u32 s50, s51",
+          "s_cbranch_scc0 2b",
+          "8:",                                           # dissolve
           "s_mov_b32 %[leaf], 0",
           "s_lshr_b32 %[cur], s52, 5",
           "s_branch 7f",
@@ -348,8 +338,8 @@ def relocate(line):
     return re.sub(r"\bs(4\d|5\d|6[0-3])\b", one, line)
 
 
-def emit_asm(K, form, ind, prefetch=False, leaf=False, deadline=False):
-    lines = loop_leaf(form, deadline) if leaf else (loop_prefetch(form) if prefetch else loop(K, form))
+def emit_asm(K, form, ind, prefetch=False, leaf=False):
+    lines = loop_leaf(form) if leaf else (loop_prefetch(form) if prefetch else loop(K, form))
     lines = [relocate(l) for l in lines]
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
     outs = ['[cur] "+s"(cur)', '[budget] "+s"(budget)', '[acc] "+s"(acc)', '[leaf] "=&s"(leaf)']
@@ -358,8 +348,6 @@ def emit_asm(K, form, ind, prefetch=False, leaf=False, deadline=False):
     outs += [f'[t{i}] "=&v"(t{i})' for i in range(15 if leaf else 7)]
     if leaf:
         outs += ['[oc0] "+s"(occluded[0])']
-    if deadline:
-        outs += ['[wl] "+s"(windowsLeft)']
     ins = ['[base] "s"(base)', '[thr] "s"(thr)', '[window] "s"(window)']
     for k in range(K):
         ins += [f'[o{a}{k}] "v"(r[{k}].o.{a})' for a in AX] + [f'[i{a}{k}] "v"(r[{k}].inv.{a})' for a in AX]
@@ -409,23 +397,6 @@ def main():
     for form in range(9):
         o.append(f"    case {form}:" if form < 8 else "    default:")
         o.append(emit_asm(1, form, "        ", leaf=True).rstrip("\n"))
-        o.append("        break;")
-    o.append("    }")
-    o.append("    return leaf;")
-    o.append("}")
-    o.append("")
-    o.append("// packetDescendLeaf for the first pass of a two-pass frame: leaves through the dissolve exit with windowsLeft < 0")
-    o.append("// once the packet has used up its coherence windows (see loop_leaf(deadline=True) in the generator).")
-    o.append("__device__ __forceinline__ uint32_t packetDescendLeafDeadline(uint32_t form, const void* base, const Ray (&r)[1],")
-    o.append("                                                            uint32_t& cur, uint64_t (&members)[1], uint32_t (&wait)[1],")
-    o.append("                                                            uint64_t (&occluded)[1], int32_t& budget, uint32_t& acc,")
-    o.append("                                                            uint32_t thr, uint32_t window, int32_t& windowsLeft) {")
-    o.append("    uint32_t leaf;")
-    o.append("    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;")
-    o.append("    switch (form) {")
-    for form in range(9):
-        o.append(f"    case {form}:" if form < 8 else "    default:")
-        o.append(emit_asm(1, form, "        ", leaf=True, deadline=True).rstrip("\n"))
         o.append("        break;")
     o.append("    }")
     o.append("    return leaf;")
