@@ -11,13 +11,16 @@ from raytracedshadows_amd import api, workloads
 import oracle as orc
 
 KERNELS = [int(v) for v in os.environ.get("KERNELS", "3,8").split(",")]
+OPTS = [kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv]      # context options, e.g. OPTS=defer_pairs=32
 for cfg in sys.argv[1:] or ["city_4k"]:
     wl = workloads.prepare_config(cfg, cache=True)
     W, H = wl.W, wl.H
     expect = orc.shadow_mask(wl.packed, wl.constants.as_array(), orc.light_from_product(wl.light, wl.constants), wl.positions, W, H)[0]
-    n = 40 if wl.spp > 1 else 200
+    n = int(os.environ.get("N", 40 if wl.spp > 1 else 200))
     with api.ShadowContext(0) as ctx:
         ctx.set_bvh(wl.packed)
+        for k_, v_ in OPTS:
+            ctx.set_option(k_, int(v_))
         d_pos, d_m = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
         ctx.h2d(d_pos, wl.positions)
         for rep in range(2):
