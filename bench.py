@@ -94,7 +94,7 @@ def _per_dispatch(csv_dir, kernel_substr="shadowMask"):
     return out
 
 
-def live_counters(args, say, config=None, kernel=None, passes=None, trace=True):
+def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, options=None):
     """Runs `bench.py --pmc-child` under rocprofv3 once per counter group; returns a dict or None."""
     config = config or args.config
     kernel = args.kernel if kernel is None else kernel
@@ -106,7 +106,7 @@ def live_counters(args, say, config=None, kernel=None, passes=None, trace=True):
     work = tempfile.mkdtemp(prefix="rts_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--kernel", str(kernel),
-             "--prewarm-seconds", "0"]
+             "--options", args.options if options is None else options, "--prewarm-seconds", "0"]
     res = {"source": "live: rocprofv3 --pmc child passes of this command in this run", "passes": []}
     t_all = time.time()
     try:
@@ -243,6 +243,7 @@ def pmc_child(args):
     with api.ShadowContext(0) as ctx:
         if args.kernel >= 0:
             ctx.set_option("kernel", args.kernel)
+        apply_options(ctx, args.options)
         d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
         ctx.h2d(d_pos, wl.positions)
         ctx.set_bvh(one)
@@ -314,25 +315,39 @@ def tune_child(args):
             ctx.trace_shadow_mask_device(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
         ctx.synchronize()
         chosen, ms = ctx.autotune(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
+        tuned = {k: ctx.get_option(k) for k in TUNED_OPTIONS}
         ctx.free(d_pos)
         ctx.free(d_mask)
-    print(json.dumps({"kernel": chosen, "ms": ms}))
+    print(json.dumps({"kernel": chosen, "ms": ms, "options": tuned}))
+
+
+TUNED_OPTIONS = ("packet_share", "row_order")       # what rts_ctx_autotune sets besides the kernel
+
+
+def options_arg(options):
+    return ",".join(f"{k}={v}" for k, v in sorted((options or {}).items()))
+
+
+def apply_options(ctx, text):
+    for kv in filter(None, (text or "").split(",")):
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
 
 
 def pick_kernel(args, config, say):
-    """Kernel id for `config`: the caller's --kernel, else the autotuner's choice (a child process: this one must not touch the
-    GPU before the profiler passes have run)."""
+    """(kernel id, launch options) for `config`: the caller's --kernel / --options, else the autotuner's choice (a child process:
+    this one must not touch the GPU before the profiler passes have run)."""
     if args.kernel >= 0:
-        return args.kernel
+        return args.kernel, args.options
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tune-child", "--config", config], cwd="/tmp",
                            capture_output=True, text=True, timeout=300)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
-        say(f"autotune [{config}]: kernel {rec['kernel']} ({rec['ms']:.4f} ms)")
-        return int(rec["kernel"])
+        say(f"autotune [{config}]: kernel {rec['kernel']}, {rec.get('options')} ({rec['ms']:.4f} ms)")
+        return int(rec["kernel"]), options_arg(rec.get("options"))
     except Exception as e:
         say(f"autotune child failed for {config} ({e!r}): library default")
-        return -1
+        return -1, args.options
 
 
 def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=0):
@@ -401,6 +416,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="city_4k")
     ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = what rts_ctx_autotune picks for the frame)")
+    ap.add_argument("--options", default="", help="context options for the traced frame, key=value,... (with --kernel; else what "
+                                                  "rts_ctx_autotune picks: packet_share, row_order)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -475,15 +492,15 @@ def main():
 
     # ---- kernel choice and counters, by child processes while this one has not touched the GPU yet ----------------
     secondary_names = [] if (N > 1 or args.no_secondary) else SECONDARY.get(args.config, [])
-    kernel_id = pick_kernel(args, args.config, say) if N == 1 else args.kernel
+    kernel_id, kernel_opts = pick_kernel(args, args.config, say) if N == 1 else (args.kernel, args.options)
     counters = None
     if N == 1 and not args.no_pmc:
-        counters = live_counters(args, say, kernel=kernel_id)
+        counters = live_counters(args, say, kernel=kernel_id, options=kernel_opts)
     secondary_plan = []
     for name in secondary_names:
-        kid = pick_kernel(args, name, say)
-        cnt = None if args.no_pmc else live_counters(args, say, config=name, kernel=kid, passes=PMC_PASSES_SECONDARY)
-        secondary_plan.append((name, kid, cnt))
+        kid, kopts = pick_kernel(args, name, say)
+        cnt = None if args.no_pmc else live_counters(args, say, config=name, kernel=kid, passes=PMC_PASSES_SECONDARY, options=kopts)
+        secondary_plan.append((name, kid, cnt, kopts))
 
     my_rows = partition.stripe_rows(H, N, rank, band=BAND, interleaved=True) if striped else [(0, H)]
     my_rays = sum(e - b for b, e in my_rows) * W * max(1, spp)
@@ -511,8 +528,11 @@ def main():
     ctx.h2d(d_mask, np.zeros((H, W), np.uint8))
     if N > 1 and args.kernel < 0:                               # every rank tunes on its own device (the full frame, untimed)
         kernel_id, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        # (a stripe is launched in row order whatever "row_order" says; the dissolve threshold is kept)
+        kernel_opts = options_arg({k: ctx.get_option(k) for k in TUNED_OPTIONS})
     if kernel_id >= 0:
         ctx.set_option("kernel", kernel_id)
+    apply_options(ctx, kernel_opts)
 
     def one_step(c=ctx):                  # ONE dispatch per step on every rank
         if striped:
@@ -583,6 +603,7 @@ def main():
         floor_ctx.set_bvh(api.BVHBuilder().build(tri, 3, np.arange(3, dtype=np.uint32), 1).m_packedNodes)
         if kernel_id >= 0:
             floor_ctx.set_option("kernel", kernel_id)
+        apply_options(floor_ctx, kernel_opts)
         for _ in range(20):
             one_step(floor_ctx)
         fl = []
@@ -626,6 +647,7 @@ def main():
                                   f"one frame row-striped over {N} GPUs in interleaved {BAND}-row bands" if striped else "one frame"),
                    "rays_per_frame": rays_per_frame, "kernel": kname,
                    "kernel_choice": "--kernel" if args.kernel >= 0 else "rts_ctx_autotune on this frame (untimed set-up)",
+                   "launch_options": kernel_opts,
                    "bvh_bytes": int(wl.packed.nbytes),
                    "ms_per_frame_gpu_median": round(max(g[2] for g in per_rank), 4),
                    "ms_per_frame_gpu_mean": round(max(g[1] for g in per_rank) / args.steps, 4),
@@ -704,7 +726,7 @@ def main():
     # ---- the other workloads (N = 1): the same protocol -- parity gate on every pixel, pre-warm, 20 timed steps -- no CPU
     #      baseline; their counters come from their own profiler passes (above) --------------------------------------------
     secondary = {}
-    for name, kid, cnt in secondary_plan:
+    for name, kid, cnt, kopts in secondary_plan:
         try:
             t_start = time.time()
             swl = workloads.prepare_config(name, cache=True, threads=host_threads, log=say)
@@ -713,6 +735,7 @@ def main():
             sctx.set_bvh(swl.packed)
             if kid >= 0:
                 sctx.set_option("kernel", kid)
+            apply_options(sctx, kopts)
             sd_pos, sd_mask = sctx.malloc(swl.positions.nbytes), sctx.malloc(sW * sH)
             sctx.h2d(sd_pos, swl.positions)
 
@@ -725,7 +748,7 @@ def main():
             sm = measure(sctx, sstep, 20, 5, args.prewarm_seconds, probe_rows=((sH + 7) // 8) if spacket else 0)
             s_avg = sm["kernel_ms"] / 1e3 / 20
             rec = {"workload": f"{name}: {workloads.CONFIGS[name][0]} ({swl.prim_count} triangles), {sW}x{sH}, {max(1, swl.spp)} spp",
-                   "kernel": sk, "parity": f"{swl.rays} rays bit-exact vs the oracle", "steps": 20, "warmup": 5,
+                   "kernel": sk, "launch_options": kopts, "parity": f"{swl.rays} rays bit-exact vs the oracle", "steps": 20, "warmup": 5,
                    "value": round(swl.rays * 20 / sm["wall"] / 1e6, 1), "unit": "Mrays/s",
                    "ms_per_frame_gpu_median": round(sm["median_ms"], 4),
                    "nodes_per_ray": round(sV / swl.rays, 2), "triangle_tests_per_ray": round(sL / swl.rays, 2),

@@ -251,9 +251,11 @@ int rts_ctx_read_wave_stats(rts_ctx* ctx, uint64_t* out, size_t waves);
  * start, at end, 100 MHz clock at start, at end} (4 x u64 per row): clock held = sum(d shader) / sum(d 100 MHz) * 100 MHz. */
 int rts_ctx_read_clock_probe(rts_ctx* ctx, uint64_t* out, size_t rows);
 /* Picks the kernel for this frame by timing the candidates on it (lane-per-ray with work sharing for small frames, the
- * packet kernel, the wide packet kernel) -- what a renderer does once per scene and resolution; leaves option "kernel" set
- * to the winner (*chosen, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
- * Results never depend on the choice. */
+ * packet kernel, the wide packet kernel) -- what a renderer does once per scene and resolution; then, for a packet kernel,
+ * the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile rows are started ("row_order" 0 or 1), each
+ * kept only if it gains 1.5 %.  Leaves the options "kernel", "packet_share" and "row_order" set to the winners (*chosen =
+ * the kernel, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
+ * Results never depend on any of the three. */
 int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
                      uint32_t W, uint32_t H, uint8_t* d_mask, int* chosen, float* ms);
 /* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks

@@ -619,36 +619,59 @@ int rts_ctx_read_clock_probe(rts_ctx* c, uint64_t* out, size_t rows) {
 
 // Picks the kernel for THIS frame by timing the candidates on it (what a renderer does once per scene and resolution):
 // the lane-per-ray walk with work sharing, the packet kernel, the wide packet kernel (when the stream has a private copy).
-// Leaves option "kernel" set to the winner.  Results never depend on the choice.
+// Then, for a packet kernel, two launch parameters that are worth 2-6 % on some frames and cost as much on others
+// (profiles/r03/autotune_stage2_sweep.log): the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile
+// rows are started ("row_order" top-down or bottom-up: the rows started last are the kernel's tail).  Leaves the three
+// options set to the winners.  Results never depend on any of them.
 int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W,
                      uint32_t H, uint8_t* d_mask, int* chosen, float* ms_out) {
     if (!c || !k || !d_positions || !d_mask) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
+    int status = RTS_OK;
+    auto median5 = [&](float* out) {          // two untimed launches, then the median of five
+        float times[5];
+        for (int i = -2; i < 5; ++i) {
+            if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return false;
+            status = rts_trace_shadow_mask_device(c, k, light, d_positions, W, H, 0, H, d_mask, nullptr);
+            if (status != RTS_OK) return false;
+            float ms = 0;
+            if (hipEventRecord(c->ev1, nullptr) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+                hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) { status = RTS_ERR_HIP; return false; }
+            if (i >= 0) times[i] = ms;
+        }
+        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
+        *out = times[2];
+        return true;
+    };
     // (the wide kernel first, and a later candidate must beat the best by 2 %: at equal frame time the wide kernel's waves
     //  are shorter, which is what a striped multi-GPU frame needs -- tools/stripe_scaling.py)
     const int candidates[3] = { rts::V_WIDE, rts::V_PACKET, rts::V_SHARE };
-    const int before = c->variant;
+    const int before = c->variant, shareBefore = c->packetShare, orderBefore = c->rowOrder;
     int best = before;
     float bestMs = 1e30f;
     for (int v : candidates) {
         if (v == rts::V_WIDE && !c->wideCount) continue;
         if (v == rts::V_SHARE && (uint64_t)W * H > (1u << 20)) continue;        // (never close on a big frame: skip its long launches)
         c->variant = v;
-        float times[5];
-        for (int i = -2; i < 5; ++i) {
-            RTS_HIP(hipEventRecord(c->ev0, nullptr));
-            int s = rts_trace_shadow_mask_device(c, k, light, d_positions, W, H, 0, H, d_mask, nullptr);
-            if (s != RTS_OK) { c->variant = before; return s; }
-            RTS_HIP(hipEventRecord(c->ev1, nullptr));
-            RTS_HIP(hipEventSynchronize(c->ev1));
-            float ms = 0;
-            RTS_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            if (i >= 0) times[i] = ms;
-        }
-        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
-        if (times[2] < bestMs * 0.98f) { bestMs = times[2]; best = v; }
+        float ms;
+        if (!median5(&ms)) { c->variant = before; return status; }
+        if (ms < bestMs * 0.98f) { bestMs = ms; best = v; }
     }
     c->variant = best;
+    if (best == rts::V_WIDE || best == rts::V_PACKET) {
+        // second stage, one parameter at a time; a change must gain 1.5 % to be kept (launch-to-launch noise is below 1 %)
+        float ms;
+        if (c->packetShare == 4) {
+            c->packetShare = 6;
+            if (!median5(&ms)) { c->packetShare = shareBefore; return status; }
+            if (ms < bestMs * 0.985f) bestMs = ms; else c->packetShare = shareBefore;
+        }
+        if (c->rowOrder == 0 && !c->d_tileOrder && !c->swizzle) {
+            c->rowOrder = 1;
+            if (!median5(&ms)) { c->rowOrder = orderBefore; return status; }
+            if (ms < bestMs * 0.985f) bestMs = ms; else c->rowOrder = orderBefore;
+        }
+    }
     if (chosen) *chosen = best;
     if (ms_out) *ms_out = bestMs;
     return RTS_OK;

@@ -509,6 +509,31 @@ def test_auto_kernel_selection_and_names(ctx):
         assert ctx.last_kernel_name() == name
 
 
+def test_autotune_leaves_legal_options_and_the_same_mask(ctx):
+    """rts_ctx_autotune picks a kernel, a dissolve threshold and a row order by timing them: whatever it picks, the mask is the
+    oracle's, and the three options hold values it may pick."""
+    try:
+        for scene, W, H in (("atrium", 960, 540), ("cornell", 200, 120)):
+            wl = workloads.prepare(scene, W, H, via_obj=False)
+            want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(),
+                                            oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+            ctx.set_bvh(wl.packed)
+            ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+            d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+            ctx.h2d(d_pos, wl.positions)
+            chosen, ms = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            assert chosen in (3, 7, 8) and ctx.get_option("kernel") == chosen and ms > 0
+            assert ctx.get_option("packet_share") in (4, 6) and ctx.get_option("row_order") in (0, 1)
+            ctx.h2d(d_mask, np.full(W * H, 9, np.uint8))
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            got = np.empty(W * H, np.uint8)
+            ctx.d2h(got, d_mask)
+            assert (got.reshape(H, W) == want).all()
+            ctx.free(d_pos); ctx.free(d_mask)
+    finally:
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+
+
 def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
     """Light inside the room: ray directions of one tile straddle the sign planes (generic form 8).  A blob whose
     inner boxes have bboxMin > bboxMax on an axis (another producer) must switch the ordered test off."""

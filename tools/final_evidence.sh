@@ -23,7 +23,8 @@ for N in 2 4; do
 done
 # rocprofv3 kernel trace + stats of the same command (probes off: only the timed kernel runs)
 KID=$(python -c "import json; print({'shadowMaskPacketKernel<1,wide>': 8}.get(json.load(open('$OUT/bench_city4k.json'))['config']['kernel'], 3))")
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --kernel $KID --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace_bench.err); echo "trace rc=$?"
+KOPT=$(python -c "import json; print(json.load(open('$OUT/bench_city4k.json'))['config'].get('launch_options', ''))")
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --kernel $KID --options "$KOPT" --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace_bench.err); echo "trace rc=$?"
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/city4k_kernel_stats.csv \;
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_courtyard -- python3 $REPO/bench.py --config courtyard_4k --kernel 8 --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_courtyard.json 2> $OUT/trace_bench_courtyard.err); echo "trace courtyard rc=$?"
 find $OUT/trace_courtyard -name "*kernel_stats.csv" -exec cp {} $OUT/courtyard4k_kernel_stats.csv \;
