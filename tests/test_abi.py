@@ -78,6 +78,28 @@ def test_generated_asm_include_is_up_to_date(tmp_path):
     assert open(gen.OUT).read() == committed
 
 
+def test_generated_wide_asm_include_is_up_to_date(tmp_path):
+    """rts_wide_asm.inc is generated too: the committed file must be what tools/gen_wide_asm.py produces."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_wide_asm", os.path.join(ROOT, "tools", "gen_wide_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "out.inc")
+    gen.main()
+    assert open(gen.OUT).read() == committed
+
+
+def test_null_arguments_are_refused_before_any_device_call():
+    """Entry points check their arguments first (RTS_ERR_INVALID_ARG = 1): callable without a GPU."""
+    lib = api._lib
+    assert lib.rts_ctx_autotune(None, None, None, None, 0, 0, None, None, None) == 1
+    assert lib.rts_ctx_set_option(None, b"kernel", 0) == 1
+    assert lib.rts_ctx_set_bvh(None, None, 0) == 1
+    assert lib.rts_trace_shadow_mask_device(None, None, None, None, 8, 8, 0, 8, None, None) == 1
+    assert lib.rts_ctx_set_tile_order(None, None, 0) == 1
+
+
 def test_plain_c_program_drives_the_host_producer(tmp_path):
     """include/*.h compile as C99 and a C program gets the Appendix-A stream out of librts.so (no GPU call)."""
     import json
