@@ -185,3 +185,30 @@ def test_roofline_arithmetic_on_the_committed_counters():
     assert none["frac"] is None and none["traffic"] is None and none["bound"] == "hbm"
     no_clock = bench.roofline_bounds(rec, 0.17e-3, None)                   # without a measured clock only the HBM bound is claimed
     assert no_clock["bound"] == "hbm" and no_clock["valu_issue"] is None
+
+
+def test_bench_passes_the_autotuners_launch_options_on_as_text():
+    """bench.py hands what rts_ctx_autotune picked (besides the kernel) to its profiler children and secondary workloads as a
+    `key=value,...` string: the round trip sets exactly those options."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = bench.options_arg({"row_order": 1, "packet_share": 6})
+    assert text == "packet_share=6,row_order=1"
+    assert bench.options_arg({}) == "" and bench.options_arg(None) == ""
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def set_option(self, k, v):
+            self.calls.append((k, v))
+
+    r = Recorder()
+    bench.apply_options(r, text)
+    assert r.calls == [("packet_share", 6), ("row_order", 1)]
+    bench.apply_options(r, "")
+    assert len(r.calls) == 2
+    assert set(bench.TUNED_OPTIONS) == {"packet_share", "row_order"}
