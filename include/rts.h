@@ -258,6 +258,42 @@ int rts_ctx_read_clock_probe(rts_ctx* ctx, uint64_t* out, size_t rows);
  * Results never depend on any of the three. */
 int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
                      uint32_t W, uint32_t H, uint8_t* d_mask, int* chosen, float* ms);
+/* ---- split tiles: the few tiles that are measured to be LONG walked by several waves -------------------------------------
+ * The reference maps one 8x8 tile to one 64-thread group (RayTracedShadows.comp:127, dispatch RayTracedShadows.cpp:590-592) and
+ * so does every kernel here; a frame's time is then often its few longest waves.  A split table breaks that mapping for
+ * exactly those tiles: each is walked by S one-wave workgroups ("pieces"), every piece over ONE index range of the node
+ * stream with all 64 rays (any-hit is an OR over the ranges; exactness: rts_kernels.hip, "SPLIT TILES").  The pieces are
+ * the first workgroups of the SAME dispatch (the longest work starts first), the split tiles' own waves end in their
+ * prologue, and launches without a table run the unchanged everyday kernels.
+ *
+ * rts_ctx_plan_splits measures and installs the table for ONE dispatch geometry (frame size and row range, or stripe):
+ *   1. wave statistics of the dispatch (one launch with "wave_stats"), or the caller's statistics of an EARLIER frame
+ *      (prev_stats / prev_realtime as rts_ctx_read_wave_stats / rts_ctx_read_wave_realtime return them, prev_waves entries);
+ *   2. the tiles whose wave lived longer than min_life_us (the longest max_tiles of them) are walked once more, alone, with
+ *      their visited node indices logged; tile t gets S = ceil(life / piece_us) pieces (2 .. max_pieces), its ranges cut at
+ *      the j/S quantiles of its log.
+ * Every later trace with the same geometry, one sample per pixel and kernel 3 or 8 uses the table (option "tile_splits" 0
+ * switches that off; get "split_tiles" / "split_pieces" = the table's size); rts_ctx_set_bvh and rts_ctx_clear_splits drop
+ * it.  The table only holds node indices and tile coordinates: a camera or light that moves makes it less well balanced,
+ * never wrong.  Needs the private copy of kernel 8 (without one no table is made: *tiles = 0).  Synchronous, default stream;
+ * device pointers.  Results never depend on any of it (tests/test_gpu_parity.py). */
+typedef struct rts_split_plan {
+    float    min_life_us;        /* > 0 */
+    float    piece_us;           /* > 0 */
+    uint32_t max_pieces;         /* 2..64 */
+    uint32_t max_tiles;          /* 0 = 4096 */
+    const uint64_t* prev_stats;  /* all three NULL / 0: measure now */
+    const uint64_t* prev_realtime;
+    size_t   prev_waves;
+} rts_split_plan;
+int rts_ctx_plan_splits(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                        uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, uint8_t* d_mask,
+                        const rts_split_plan* plan, uint32_t* tiles, uint32_t* pieces);
+/* ... for the dispatch of rts_trace_shadow_mask_stripes_device with the same band_rows / n_stripes / stripe */
+int rts_ctx_plan_splits_stripes(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                                uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                                const rts_split_plan* plan, uint32_t* tiles, uint32_t* pieces);
+int rts_ctx_clear_splits(rts_ctx* ctx);
 /* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks
  * from the wave's start to its first ray being ready (G-buffer texel in, ray set up), XCC id.  With the start/end shader
  * clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */

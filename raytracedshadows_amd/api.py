@@ -151,6 +151,19 @@ _sig("rts_stream_create", C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
 _sig("rts_stream_destroy", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
      C.POINTER(C.c_int), C.POINTER(C.c_float))
+
+
+class SplitPlan(C.Structure):
+    """rts_split_plan (include/rts.h)."""
+    _fields_ = [("min_life_us", C.c_float), ("piece_us", C.c_float), ("max_pieces", C.c_uint32), ("max_tiles", C.c_uint32),
+                ("prev_stats", C.c_void_p), ("prev_realtime", C.c_void_p), ("prev_waves", C.c_size_t)]
+
+
+_sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32, C.c_uint32,
+     C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_sig("rts_ctx_plan_splits_stripes", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32,
+     C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_sig("rts_ctx_clear_splits", C.c_int, C.c_void_p)
 _sig("rts_timer_mark", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
 _sig("rts_timer_between_ms", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 _sig("rts_device_mem_info", C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
@@ -430,6 +443,32 @@ class ShadowContext:
         _check(_lib.rts_ctx_autotune(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
                                      C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)), "rts_ctx_autotune")
         return int(chosen.value), float(ms.value)
+
+    def plan_splits(self, constants, d_positions, width, height, d_mask, light=None, min_life_us=20.0, piece_us=10.0,
+                    max_pieces=8, max_tiles=0, row_begin=0, row_end=None, stripes=None, prev=None):
+        """rts_ctx_plan_splits(_stripes): measures the dispatch, installs the split table; returns (tiles, pieces).
+        stripes = (band_rows, n_stripes, stripe) plans the interleaved-stripe dispatch; prev = (stats, realtime) arrays of an
+        earlier frame (read_wave_stats / read_wave_realtime) instead of a measuring launch."""
+        plan = SplitPlan(min_life_us, piece_us, max_pieces, max_tiles, None, None, 0)
+        keep = None
+        if prev is not None:
+            keep = (np.ascontiguousarray(prev[0], np.uint64), np.ascontiguousarray(prev[1], np.uint64))
+            plan.prev_stats, plan.prev_realtime, plan.prev_waves = keep[0].ctypes.data, keep[1].ctypes.data, keep[0].size // 4
+        tiles, pieces = C.c_uint32(0), C.c_uint32(0)
+        lp = C.byref(light) if light is not None else None
+        if stripes is not None:
+            _check(_lib.rts_ctx_plan_splits_stripes(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
+                                                    stripes[0], stripes[1], stripes[2], C.c_void_p(d_mask), C.byref(plan),
+                                                    C.byref(tiles), C.byref(pieces)), "rts_ctx_plan_splits_stripes")
+        else:
+            row_end = height if row_end is None else row_end
+            _check(_lib.rts_ctx_plan_splits(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height, row_begin,
+                                            row_end, C.c_void_p(d_mask), C.byref(plan), C.byref(tiles), C.byref(pieces)),
+                   "rts_ctx_plan_splits")
+        return int(tiles.value), int(pieces.value)
+
+    def clear_splits(self):
+        _check(_lib.rts_ctx_clear_splits(self._h), "rts_ctx_clear_splits")
 
     def clock_probe_mhz(self, rows):
         """Shader clock held during the launches since set_option("clock_probe", rows) (the timed launches themselves)."""

@@ -4,6 +4,7 @@
 #include "bvh_builder.h"
 #include "rts_device.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,6 +49,23 @@ struct rts_ctx {
     int softSplit = 1;                       // option "soft_split": soft shadows with 4 waves per tile (samples side by side)
     uint32_t pixelBase = 0;                  // set around a host-pointer stripe (see rts_trace_shadow_mask)
     uint64_t* d_clockProbe = nullptr; size_t clockProbeRows = 0;    // option "clock_probe"
+    // split table (rts_ctx_plan_splits): valid for ONE dispatch geometry (the key), used by every trace that matches it
+    struct Splits {
+        bool valid = false;
+        uint32_t W = 0, H = 0, rowBegin = 0, rowEnd = 0, bandRows = 0, nStripes = 0, stripe = 0, blocksX = 0, blocksY = 0;
+        uint32_t* d_skipMap = nullptr;       // one bit per tile of the dispatch
+        uint32_t* d_pieces = nullptr;        // 4 dwords per piece
+        uint32_t nPieces = 0, pieceRows = 0, nTiles = 0;
+        // {occluded lanes, pieces done} per split tile: one buffer per stream that traces with the table, so that frames in
+        // flight on different streams never meet in it (frames on one stream follow each other)
+        std::vector<std::pair<void*, uint64_t*>> state;
+    } splits;
+    int useSplits = 1;                       // option "tile_splits": 0 ignores an installed table
+    struct Planning {                        // set by rts_ctx_plan_splits around its pieces-only launch
+        const uint32_t* d_pieces; uint32_t nPieces, pieceRows; uint64_t* d_state; uint32_t* d_log; uint32_t logCap;
+    };
+    const Planning* planning = nullptr;
+    uint32_t lastBlocksX = 0, lastBlocksY = 0; int lastVariant = 0; bool lastGrid2d = false;   // of the last mask dispatch
 };
 
 namespace {
@@ -71,6 +89,26 @@ int ensure(void** p, size_t* have, size_t want) {
     if (e != hipSuccess) { *p = nullptr; return hipStatus(e); }
     *have = want;
     return RTS_OK;
+}
+
+void clearSplits(rts_ctx* c) {
+    rts_ctx::Splits& t = c->splits;
+    if (t.d_skipMap) (void)hipFree(t.d_skipMap);
+    if (t.d_pieces) (void)hipFree(t.d_pieces);
+    for (auto& e : t.state) if (e.second) (void)hipFree(e.second);
+    t = rts_ctx::Splits();
+}
+
+// the {occluded, done} words of the split tiles for traces on `stream` (zeroed once; every launch leaves them zero)
+uint64_t* splitState(rts_ctx* c, void* stream) {
+    rts_ctx::Splits& t = c->splits;
+    for (auto& e : t.state) if (e.first == stream) return e.second;
+    if (t.state.size() >= 8) return nullptr;                       // more streams than that trace without the table
+    uint64_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)t.nTiles * 16 + 16) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(d, 0, (size_t)t.nTiles * 16 + 16) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    try { t.state.emplace_back(stream, d); } catch (...) { (void)hipFree(d); return nullptr; }
+    return d;
 }
 
 int fillParams(rts_ctx* ctx, TraceParams& p) {
@@ -118,7 +156,9 @@ int finishInstall(rts_ctx* c, bool freeOnRefusal) {
     if (!scratch) return RTS_OK;                      // no memory for the copy: the stackless kernels need none
     // (trees deeper than 512 levels -- chains of single-triangle splits -- keep the stackless kernels)
     e = rts::buildWideDevice(c->d_bvh, c->P, c->d_wide, c->d_tris, c->d_parents, scratch, 512, &c->wideCount, &c->wideLevels);
-    if (e != hipSuccess) { c->wideCount = 0; return hipStatus(e); }
+    // a failure here only costs the private copy: the stream itself is installed and valid, the stackless kernels need
+    // nothing else.  (Returning the error would leave the caller of the adopt path freeing a stream the context still holds.)
+    if (e != hipSuccess) { c->wideCount = 0; c->wideLevels = 0; (void)hipGetLastError(); }
     return RTS_OK;
 }
 
@@ -216,6 +256,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_word) (void)hipFree(c->d_word);
     if (c->d_clockProbe) (void)hipFree(c->d_clockProbe);
+    clearSplits(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -237,6 +278,7 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     hipError_t e = hipMemcpy(d, packed, count * 16, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return hipStatus(e); }
     c->d_bvh = d; c->bvhVec4 = count; c->P = P;
+    clearSplits(c);                      // (a split table holds node indices of the stream it was planned on)
     return finishInstall(c, true);       // finite / ordered / enclosed are decided on the device; private wide copy
 }
 
@@ -259,6 +301,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
+    if (!strcmp(key, "tile_splits")) { c->useSplits = value ? 1 : 0; return RTS_OK; }     // 0: traces ignore an installed split table
     if (!strcmp(key, "clock_probe")) {          // value = tile rows to stamp (0 = off); packet kernels on 2-D grids
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_clockProbe) { RTS_HIP(hipFree(c->d_clockProbe)); c->d_clockProbe = nullptr; c->clockProbeRows = 0; }
@@ -299,6 +342,9 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "wide_lane")) { *value = c->wideLane; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { *value = c->softSplit; return RTS_OK; }
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
+    if (!strcmp(key, "tile_splits")) { *value = c->useSplits; return RTS_OK; }
+    if (!strcmp(key, "split_tiles")) { *value = c->splits.valid ? (int)c->splits.nTiles : 0; return RTS_OK; }
+    if (!strcmp(key, "split_pieces")) { *value = c->splits.valid ? (int)c->splits.nPieces : 0; return RTS_OK; }
     if (!strcmp(key, "wide_levels")) { *value = (int)c->wideLevels; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
 }
@@ -369,6 +415,31 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.lightType = RTS_LIGHT_DIRECTIONAL;
         p.nsamples = 1;
         for (int i = 0; i < 3; ++i) p.light[i] = k->lightDirection[i];
+    }
+    c->lastBlocksX = p.blocksX; c->lastBlocksY = p.blocksY; c->lastVariant = variant; c->lastGrid2d = p.grid2d != 0;
+    if (c->planning) {                       // pieces only: the planning walk of the selected tiles, with visit logs
+        if (!(variant == rts::V_PACKET || variant == rts::V_WIDE) || c->blockWaves != 1 || p.nsamples != 1 || !p.grid2d || !p.wide ||
+            (n_stripes > 1 && p.bandShift == 0xFFFFFFFFu))
+            return RTS_ERR_INVALID_ARG;
+        p.waveStats = nullptr; p.waveRealtime = nullptr; p.clockProbe = nullptr; p.rowOrder = 0;
+        p.skipMap = c->planning->d_pieces;   // (never read: no tile rows in this launch)
+        p.pieces = c->planning->d_pieces; p.nPieces = c->planning->nPieces; p.pieceRows = c->planning->pieceRows;
+        p.tileState = c->planning->d_state; p.pieceLog = c->planning->d_log; p.pieceLogCap = c->planning->logCap;
+        p.blocksY = 0;
+        return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, 0));
+    }
+    // split table: only the everyday one-tile packet launches of the very dispatch it was planned for
+    const rts_ctx::Splits& sp = c->splits;
+    if (sp.valid && c->useSplits && sp.nPieces && (variant == rts::V_PACKET || variant == rts::V_WIDE) && c->blockWaves == 1 &&
+        p.nsamples == 1 && p.grid2d && !p.waveStats && !c->wideLane && p.wide &&
+        (n_stripes <= 1 || (p.bandShift != 0xFFFFFFFFu && p.rowOrder == 0)) &&
+        sp.W == W && sp.H == H && sp.rowBegin == row_begin && sp.rowEnd == row_end && sp.bandRows == band_rows &&
+        sp.nStripes == n_stripes && sp.stripe == stripe && sp.blocksX == p.blocksX && sp.blocksY == p.blocksY &&
+        p.blocksY + sp.pieceRows <= 65535u) {
+        if (uint64_t* st = splitState(c, stream)) {
+            p.skipMap = sp.d_skipMap; p.pieces = sp.d_pieces; p.nPieces = sp.nPieces; p.pieceRows = sp.pieceRows;
+            p.tileState = st;
+        }
     }
     c->lastKernel = rts::kernelName(variant, true);
     ++c->launches;
@@ -572,6 +643,7 @@ int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t 
     if (c->d_bvh) { void* old = c->d_bvh; c->d_bvh = nullptr; c->bvhVec4 = 0; c->P = 0; RTS_HIP(hipFree(old)); }
     c->d_bvh = d_packed;
     c->bvhVec4 = count; c->P = P;
+    clearSplits(c);
     // the same checks as for an uploaded stream, on the device: layout, finiteness (edges of finite vertices can
     // overflow), box order, enclosure.  A refused stream stays the caller's to free.
     return finishInstall(c, false);
@@ -631,12 +703,15 @@ int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light,
     auto median5 = [&](float* out) {          // two untimed launches, then the median of five
         float times[5];
         for (int i = -2; i < 5; ++i) {
-            if (hipEventRecord(c->ev0, nullptr) != hipSuccess) return false;
+            hipError_t e = hipEventRecord(c->ev0, nullptr);
+            if (e != hipSuccess) { status = hipStatus(e); return false; }
             status = rts_trace_shadow_mask_device(c, k, light, d_positions, W, H, 0, H, d_mask, nullptr);
             if (status != RTS_OK) return false;
             float ms = 0;
-            if (hipEventRecord(c->ev1, nullptr) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
-                hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) { status = RTS_ERR_HIP; return false; }
+            e = hipEventRecord(c->ev1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            if (e != hipSuccess) { status = hipStatus(e); return false; }
             if (i >= 0) times[i] = ms;
         }
         for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
@@ -654,7 +729,7 @@ int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light,
         if (v == rts::V_SHARE && (uint64_t)W * H > (1u << 20)) continue;        // (never close on a big frame: skip its long launches)
         c->variant = v;
         float ms;
-        if (!median5(&ms)) { c->variant = before; return status; }
+        if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
         if (ms < bestMs * 0.98f) { bestMs = ms; best = v; }
     }
     c->variant = best;
@@ -663,17 +738,177 @@ int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light,
         float ms;
         if (c->packetShare == 4) {
             c->packetShare = 6;
-            if (!median5(&ms)) { c->packetShare = shareBefore; return status; }
+            if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
             if (ms < bestMs * 0.985f) bestMs = ms; else c->packetShare = shareBefore;
         }
         if (c->rowOrder == 0 && !c->d_tileOrder && !c->swizzle) {
             c->rowOrder = 1;
-            if (!median5(&ms)) { c->rowOrder = orderBefore; return status; }
+            if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
             if (ms < bestMs * 0.985f) bestMs = ms; else c->rowOrder = orderBefore;
         }
     }
     if (chosen) *chosen = best;
     if (ms_out) *ms_out = bestMs;
+    return RTS_OK;
+}
+
+// Plans the split table for ONE dispatch geometry (see include/rts.h).  Synchronous, default stream.
+static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                          uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                          const rts_split_plan* plan, uint32_t* tiles_out, uint32_t* pieces_out) {
+    if (tiles_out) *tiles_out = 0;
+    if (pieces_out) *pieces_out = 0;
+    if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f)) return RTS_ERR_INVALID_ARG;
+    if (light && light->nsamples > 1) return RTS_ERR_INVALID_ARG;               // (soft shadows are dealt over waves by "soft_split")
+    RTS_HIP(hipSetDevice(c->device));
+    clearSplits(c);
+    if (!c->wideCount) return RTS_OK;                                            // pieces walk the private copy: none, no table
+    const uint32_t maxPieces = plan->max_pieces < 2 ? 2 : (plan->max_pieces > 64 ? 64 : plan->max_pieces);
+    const uint32_t maxTiles = plan->max_tiles ? (plan->max_tiles > 65536u ? 65536u : plan->max_tiles) : 4096u;
+    const uint32_t logCap = 16384;
+    int status = RTS_OK;
+    std::vector<uint64_t> stats, rt;
+    size_t waves = 0;
+    try {
+        if (plan->prev_stats && plan->prev_realtime && plan->prev_waves) {      // the caller's statistics of an earlier frame
+            waves = plan->prev_waves;
+            stats.assign(plan->prev_stats, plan->prev_stats + waves * 4);
+            rt.assign(plan->prev_realtime, plan->prev_realtime + waves * 4);
+        } else {                                                                 // one launch of this dispatch with wave statistics
+            uint64_t* keep = c->d_waveStats; const size_t keepBytes = c->waveStatsBytes;
+            c->d_waveStats = nullptr; c->waveStatsBytes = 0;
+            uint32_t rows = row_end - row_begin;
+            if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
+            waves = (size_t)((W + 7) / 8) * ((rows + 7) / 8);
+            hipError_t e = hipMalloc((void**)&c->d_waveStats, waves * 64);
+            if (e == hipSuccess) e = hipMemset(c->d_waveStats, 0, waves * 64);
+            if (e == hipSuccess) {
+                c->waveStatsBytes = waves * 32;
+                const int use = c->useSplits; c->useSplits = 0;
+                for (int i = 0; i < 2 && status == RTS_OK; ++i)                   // (the second launch is the one that counts: warm caches)
+                    status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+                c->useSplits = use;
+                if (status == RTS_OK) e = hipDeviceSynchronize();
+                if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = RTS_ERR_INVALID_ARG;   // not an 8x8-tile kernel
+                if (status == RTS_OK && e == hipSuccess) {
+                    stats.resize(waves * 4); rt.resize(waves * 4);
+                    e = hipMemcpy(stats.data(), c->d_waveStats, waves * 32, hipMemcpyDeviceToHost);
+                    if (e == hipSuccess) e = hipMemcpy(rt.data(), c->d_waveStats + waves * 4, waves * 32, hipMemcpyDeviceToHost);
+                }
+            }
+            if (c->d_waveStats) (void)hipFree(c->d_waveStats);
+            c->d_waveStats = keep; c->waveStatsBytes = keepBytes;
+            if (status != RTS_OK) return status;
+            if (e != hipSuccess) return hipStatus(e);
+        }
+        // the tiles whose wave lived longer than min_life_us, longest first
+        struct Sel { float us; uint32_t tile; };
+        std::vector<Sel> sel;
+        const uint32_t blocksX = (W + 7) / 8;
+        uint32_t blocksY = 0;
+        for (size_t i = 0; i < waves; ++i) {
+            const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
+            if (r1 <= r0) continue;
+            const float us = (float)(r1 - r0) * 0.01f;
+            const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
+            if (by >= blocksY) blocksY = by + 1;
+            if (us > plan->min_life_us && bx < blocksX) sel.push_back({ us, bx | (by << 16) });
+        }
+        if (sel.empty()) return RTS_OK;
+        std::sort(sel.begin(), sel.end(), [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); });
+        if (sel.size() > maxTiles) sel.resize(maxTiles);
+        const uint32_t T = (uint32_t)sel.size();
+        std::vector<rts::SplitCut> cuts(T);
+        std::vector<uint32_t> first(T), provisional((size_t)T * 4);
+        uint32_t nPieces = 0;
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t S = (uint32_t)std::ceil(sel[t].us / plan->piece_us);
+            S = S < 2 ? 2 : (S > maxPieces ? maxPieces : S);
+            cuts[t] = { sel[t].tile, S };
+            first[t] = nPieces;
+            nPieces += S;
+            provisional[(size_t)t * 4 + 0] = sel[t].tile; provisional[(size_t)t * 4 + 1] = 0; provisional[(size_t)t * 4 + 2] = 0xFFFFFFFFu;
+            provisional[(size_t)t * 4 + 3] = t | (1u << 24);
+        }
+        // the dispatch this table belongs to (what traceMaskImpl will compute for the same arguments)
+        uint32_t rows = row_end - row_begin;
+        if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
+        const uint32_t keyBlocksY = (rows + 7) / 8;
+        if (blocksY > keyBlocksY) return RTS_ERR_INVALID_ARG;                     // statistics of another dispatch
+        std::vector<uint32_t> bitmap(((size_t)blocksX * keyBlocksY + 31) / 32 + 1, 0u);
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t id = (sel[t].tile >> 16) * blocksX + (sel[t].tile & 0xFFFFu);
+            bitmap[id >> 5] |= 1u << (id & 31u);
+        }
+        // device side: planning walk of the selected tiles (one piece each, everything logged), then the quantiles
+        void *d_cuts = nullptr, *d_first = nullptr, *d_prov = nullptr, *d_log = nullptr, *d_state = nullptr, *d_pieces = nullptr, *d_map = nullptr;
+        const size_t logBytes = (size_t)T * (logCap + 1) * 4;
+        hipError_t e = hipMalloc(&d_cuts, (size_t)T * 8);
+        if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)T * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_prov, (size_t)T * 16);
+        if (e == hipSuccess) e = hipMalloc(&d_log, logBytes);
+        if (e == hipSuccess) e = hipMalloc(&d_state, (size_t)T * 16);
+        if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)nPieces * 16);
+        if (e == hipSuccess) e = hipMalloc(&d_map, bitmap.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(d_cuts, cuts.data(), (size_t)T * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_first, first.data(), (size_t)T * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_prov, provisional.data(), (size_t)T * 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_map, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_log, 0, logBytes);
+        if (e == hipSuccess) e = hipMemset(d_state, 0, (size_t)T * 16);
+        if (e == hipSuccess) {
+            const rts_ctx::Planning pl{ (const uint32_t*)d_prov, T, (T + blocksX - 1) / blocksX, (uint64_t*)d_state, (uint32_t*)d_log, logCap };
+            c->planning = &pl;
+            status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+            c->planning = nullptr;
+            if (status == RTS_OK) e = rts::launchSplitQuantiles((const uint32_t*)d_log, logCap, (const rts::SplitCut*)d_cuts, (const uint32_t*)d_first,
+                                                                T, (uint32_t*)d_pieces, nullptr);
+            if (status == RTS_OK && e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (d_cuts) (void)hipFree(d_cuts);
+        if (d_first) (void)hipFree(d_first);
+        if (d_prov) (void)hipFree(d_prov);
+        if (d_log) (void)hipFree(d_log);
+        if (d_state) (void)hipFree(d_state);
+        if (status != RTS_OK || e != hipSuccess) {
+            if (d_pieces) (void)hipFree(d_pieces);
+            if (d_map) (void)hipFree(d_map);
+            (void)hipGetLastError();
+            return status != RTS_OK ? status : hipStatus(e);
+        }
+        rts_ctx::Splits& t = c->splits;
+        t.valid = true;
+        t.W = W; t.H = H; t.rowBegin = row_begin; t.rowEnd = row_end; t.bandRows = band_rows; t.nStripes = n_stripes; t.stripe = stripe;
+        t.blocksX = blocksX; t.blocksY = keyBlocksY;
+        t.d_skipMap = (uint32_t*)d_map; t.d_pieces = (uint32_t*)d_pieces;
+        t.nPieces = nPieces; t.pieceRows = (nPieces + blocksX - 1) / blocksX; t.nTiles = T;
+        if (tiles_out) *tiles_out = T;
+        if (pieces_out) *pieces_out = nPieces;
+    } catch (...) {
+        c->planning = nullptr;
+        return RTS_ERR_CAPACITY;                       // no exception crosses the C ABI
+    }
+    return RTS_OK;
+}
+
+int rts_ctx_plan_splits(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                        uint32_t row_begin, uint32_t row_end, uint8_t* d_mask, const rts_split_plan* plan, uint32_t* tiles, uint32_t* pieces) {
+    if (W == 0 || H == 0 || row_begin >= row_end || row_end > H) return RTS_ERR_INVALID_ARG;
+    return planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, 0, 1, 0, d_mask, plan, tiles, pieces);
+}
+
+int rts_ctx_plan_splits_stripes(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                                uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, const rts_split_plan* plan,
+                                uint32_t* tiles, uint32_t* pieces) {
+    if (W == 0 || H == 0 || band_rows == 0 || band_rows % 8 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
+    if (n_stripes == 1) return planSplitsImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, plan, tiles, pieces);
+    return planSplitsImpl(c, k, light, d_positions, W, H, 0, H, band_rows, n_stripes, stripe, d_mask, plan, tiles, pieces);
+}
+
+int rts_ctx_clear_splits(rts_ctx* c) {
+    if (!c) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    clearSplits(c);
     return RTS_OK;
 }
 

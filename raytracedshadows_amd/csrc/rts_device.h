@@ -60,12 +60,28 @@ struct TraceParams {
     uint32_t wideBytes;       // size of the private copy (wide nodes + triangle records, one allocation)
     uint32_t trisOffset;      // byte offset of the triangle records in it (tris == wide + trisOffset)
     uint32_t wideLane;        // dissolved wide packets continue lane per ray over the WIDE nodes (0: over the stream, stackless)
+    // split tiles (rts_ctx_plan_splits): tiles measured to be long are walked by several one-wave workgroups ("pieces"), each
+    // over one index range of the node stream; the pieces occupy the first pieceRows rows of the 2-D grid (dispatched first)
+    const uint32_t* skipMap;  // bit (by * blocksX + bx) set: the tile's own wave ends in its prologue (NULL: no split table)
+    const uint32_t* pieces;   // 4 dwords per piece: {bx | by << 16, first node, end node, state slot | pieces of the tile << 24}
+    uint64_t* tileState;      // 2 u64 per split tile {lanes found occluded by any piece, pieces done}; zero between launches
+    uint32_t* pieceLog;       // split planning only: per piece 1 + pieceLogCap dwords {count, node indices visited ...}
+    uint32_t nPieces, pieceRows, pieceLogCap;
     float offsets[64][4];
+};
+
+struct SplitCut {             // planning: one selected tile
+    uint32_t tile;            // bx | by << 16 (tile coordinates of the dispatch)
+    uint32_t pieces;          // S
 };
 
 const char* kernelName(int variant, bool mask);
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH);   // pixels covered by one block
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad = 0);
 hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream);
+// planning: from the visit logs of `tiles` one-piece walks (p.pieceLog layout) to the piece table: tile t gets cuts[t].pieces
+// records starting at record firstPiece[t], its index ranges cut at the quantiles of its log
+hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const SplitCut* d_cuts, const uint32_t* d_firstPiece,
+                                uint32_t tiles, uint32_t* d_pieces, hipStream_t stream);
 
 } // namespace rts

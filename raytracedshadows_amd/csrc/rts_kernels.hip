@@ -190,6 +190,25 @@ static constexpr uint32_t OOB_VEC4 = 0x0FFFFFF0u;      // vec4 index whose byte 
 
 __device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// What the PIECES of one split tile share (see traversePiece): two words of device memory touched with relaxed agent-scope
+// atomics only (the pieces of a tile are one-wave workgroups that may run on different XCDs).  Nobody ever waits on them:
+// state[0] collects the lanes (= rays of the tile) some piece found occluded -- a piece asks for it every few steps and drops
+// those rays, the request travelling while the walk goes on --, state[1] counts the pieces that are done.
+struct PieceShare {
+    uint64_t* state = nullptr;
+    uint64_t seen = 0;              // state[0] as of the previous request
+    uint32_t* log = nullptr;        // split planning only: visit log of this piece {count, node indices ...}
+    uint32_t logCap = 0, logCount = 0;
+    __device__ __forceinline__ uint64_t poll() {
+        const uint64_t got = seen;
+        seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+    }
+    __device__ __forceinline__ void publish(uint64_t lanes) {
+        if (laneId() == 0) (void)__hip_atomic_fetch_or(state, lanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the loop and active lanes summed over them
     bool on = false;
     uint32_t iterations = 0, laneSteps = 0;
@@ -200,10 +219,13 @@ struct ShareDiag {              // diagnostics ("wave_stats"): iterations of the
 // subtree whose root box it does not hit by the exact test, and reach a leaf there through a miss link.  A triangle hit
 // then only counts if the ray hits the box of the leaf's PARENT by the exact test -- by the enclosure property that is
 // "the reference's walk reaches this leaf" (rts_wide.hip).  The parent's index comes from the private parent table.
-template <bool FAST, bool CONFIRM = false>
+// TEAM (a piece of a split tile): the walk ends at `bound0`, owners that another piece found occluded are dropped (polled every
+// fourth iteration), owners found occluded here are published.
+template <bool FAST, bool CONFIRM = false, bool TEAM = false>
 __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool live, uint32_t start, uint32_t* ldsSlots,
-                                              ShareDiag* diag = nullptr, const uint32_t* parents = nullptr) {
-    uint32_t node = live ? start : END, bound = END, owner = laneId();
+                                              ShareDiag* diag = nullptr, const uint32_t* parents = nullptr, uint32_t bound0 = END,
+                                              PieceShare* team = nullptr) {
+    uint32_t node = live ? start : END, bound = bound0, owner = laneId();
     uint64_t occludedOwners = 0;                       // wave-uniform
     uint32_t iter = 0;
     // The loop is rotated: the node of the NEXT iteration is requested before the triangle of this one is tested.
@@ -217,9 +239,24 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
     bool active = node < bound;
     u32x4 a = bvh.vec4(active ? node * 2u : OOB_VEC4), b = bvh.vec4(active ? node * 2u + 1u : OOB_VEC4);
     for (;;) {
+        if constexpr (TEAM) {
+            if ((iter & 3u) == 0) {
+                occludedOwners |= team->poll();
+                active = active && !((occludedOwners >> owner) & 1ull);
+            }
+        }
         const uint64_t act = __builtin_amdgcn_ballot_w64(active);
         if (act == 0) break;
         if (diag && diag->on) { diag->iterations += 1u; diag->laneSteps += (uint32_t)__builtin_popcountll(act); }
+        if constexpr (TEAM) {
+            if (team->log) {                                          // planning: a quarter of the visits, rotating over the lanes
+                const bool sel = active && (((laneId() + iter) & 3u) == 0);
+                const uint64_t m = __builtin_amdgcn_ballot_w64(sel);
+                const uint32_t at = team->logCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (sel && at < team->logCap) team->log[1u + at] = node;
+                team->logCount += (uint32_t)__builtin_popcountll(m);
+            }
+        }
         uint32_t next = node;                                        // lanes that do not move keep their (finished) range
         if ((iter++ & 3u) == 0) {
             const uint64_t idle = ~act;
@@ -286,6 +323,11 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
                                   __uint_as_float(pb.x), __uint_as_float(pb.y), __uint_as_float(pb.z));
         }
         uint64_t hits = __builtin_amdgcn_ballot_w64(hitNow);
+        if (TEAM && hits) {
+            uint64_t fresh = 0;
+            for (uint64_t hm = hits; hm; hm &= hm - 1) fresh |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)owner, __builtin_ctzll(hm));
+            team->publish(fresh);
+        }
         while (hits) {                                               // rare: record the owners that just got occluded
             const int l = __builtin_ctzll(hits);
             occludedOwners |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)owner, l);
@@ -780,7 +822,9 @@ __device__ __forceinline__ bool wideDissolve(const TraceParams& p, const NodeStr
 
 #include "rts_wide_asm.inc"
 
-static constexpr uint32_t WIDE_STACK_LIMIT = 60;   // entries on the stack when a node is taken up (it pushes at most 3)
+// entries on the stack when a node is taken up: it pushes at most 3 and a dissolve one more, and lane 63 of the stack
+// registers is not the stack's in the assembly form (it keeps EXEC) -- the same limit in both forms
+static constexpr uint32_t WIDE_STACK_LIMIT = 59;
 
 template <int OCT>
 __device__ __forceinline__ bool wideWalk(const TraceParams& p, const NodeStream& bvh, const Ray& r, const WideRay& w,
@@ -908,6 +952,150 @@ __device__ __forceinline__ bool traverseWide(const TraceParams& p, const NodeStr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SPLIT TILES: a tile that was measured to be long (rts_ctx_plan_splits) is walked by S one-wave workgroups, the PIECES.
+// Every piece sets up all 64 rays of the tile and walks ONE index range [a, b) of the node stream; the ranges partition
+// [0, N) at the quantiles of the visit log of a planning walk, so that each holds about 1/S of the tile's work.
+//
+// Why any cut is exact.  Wide nodes are numbered in stream order and a subtree is a contiguous index range, so "slot k's
+// subtree is [index of slot k, index of slot k + 1)" (rts_wide.hip, dwords 28..31) lets the walk skip every subtree that lies
+// outside [a, b); what it enters is culled with the conservative test as everywhere in the wide kernels, a triangle is tested
+// by the piece whose range holds its leaf (a neighbour may test it again: any-hit is an OR), and a triangle HIT counts iff
+// the ray hits the box of the leaf's parent by the exact test -- which by the enclosure property is "the reference's walk
+// reaches this leaf" (rts_wide.hip).  The OR over the pieces is therefore the reference's any-hit (comp:75-111).  After a
+// dissolve each ray continues the stackless walk from max(its lowest pending node, a) up to b, hits confirmed the same way.
+// A wave with a ray the conservative test is not proven for (NaN / overflow possible) is walked whole, exactly, by piece 0.
+//
+// What the pieces share: PieceShare (two words of device memory, nobody waits).  The piece that finishes last stores the
+// tile's 64 bytes and leaves the two words zero for the next launch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const NodeStream& bvh, const Ray& r, const WideRay& w, uint64_t liveMask,
+                                                  uint32_t a, uint32_t b, PieceShare& team, uint32_t* lds) {
+    const uint64_t wideAddr = uniform64(p.wide), triAddr = uniform64(p.tris);
+    uint32_t stRef = 0, stLo = 0, stHi = 0;            // the stack: entry i lives in lane i (as in wideWalk)
+    uint32_t sp = 0;
+    uint64_t occ = 0;
+    uint32_t curRef = 0;
+    uint64_t curM = liveMask;
+    bool have = true, dissolve = false;
+    const uint32_t window = p.packetBudget, thr = p.packetBudget * p.packetShare;
+    uint32_t acc = 0, left = window, pollLeft = 1;
+    auto push = [&](uint32_t ref, uint64_t m) {
+        asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+                     : "+v"(stRef), "+v"(stLo), "+v"(stHi)
+                     : "s"(ref), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(sp)
+                     : "m0");
+        ++sp;
+    };
+    auto entryMask = [&](uint32_t e) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)stHi, (int)e) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)stLo, (int)e);
+    };
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            curRef = (uint32_t)__builtin_amdgcn_readlane((int)stRef, (int)sp);
+            curM = entryMask(sp) & ~occ;
+            if (curM == 0) continue;
+        }
+        have = false;
+        if (--pollLeft == 0) {                                          // rays another piece found occluded (as of four nodes ago)
+            pollLeft = 4;
+            occ |= team.poll();
+            if ((liveMask & ~occ) == 0) { sp = 0; break; }
+            curM &= ~occ;
+            if (curM == 0) continue;
+        }
+        acc += (uint32_t)__builtin_popcountll(curM);
+        if (--left == 0) {
+            const uint32_t alive = (uint32_t)__builtin_popcountll(liveMask & ~occ);
+            dissolve = acc * 16u < alive * thr;
+            acc = 0; left = window;
+        }
+        if (dissolve || sp > WIDE_STACK_LIMIT) { push(curRef, curM); dissolve = true; break; }
+        const ConstWidePtr np = (ConstWidePtr)(uintptr_t)(wideAddr + curRef);
+        const u32x16 n0 = np[0], n1 = np[1];
+        float pl[24];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) pl[d] = __uint_as_float(n0[d]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) pl[16 + d] = __uint_as_float(n1[d]);
+        const uint32_t ref[4] = { n1[8], n1[9], n1[10], n1[11] };
+        const uint32_t self = n1[12];
+        const uint32_t idx[4] = { self + 1u, n1[13], n1[14], n1[15] };   // first node of slot k's subtree (slot 0: a lower bound)
+        if (team.log) {                                                   // planning: a packet node weighs eight lane visits
+            const uint32_t at = team.logCount + laneId();
+            if (laneId() < 8u && at < team.logCap) team.log[1u + at] = self;
+            team.logCount += 8u;
+        }
+        uint64_t h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool in;
+            if (ref[k] == END) in = false;
+            else if (ref[k] & 1u) in = k == 0 ? (self + 2u >= a && self + 1u < b) : (idx[k] >= a && idx[k] < b);
+            else in = idx[k] < b && (k == 3 || ref[k == 3 ? 3 : k + 1] == END || idx[k == 3 ? 3 : k + 1] > a);
+            h[k] = in ? (__builtin_amdgcn_ballot_w64(cheapBox<8>(&pl[6 * k], &pl[6 * k + 3], r.inv, w)) & curM) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                   // leaf slots somebody hit: one triangle each
+            if (h[k] == 0 || !(ref[k] & 1u)) continue;
+            const ConstVec4Ptr tp = (ConstVec4Ptr)(uintptr_t)(triAddr + (ref[k] - 1u));
+            const u32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const F3 v0{ __uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z) };
+            const F3 e0{ __uint_as_float(t0.w), __uint_as_float(t1.x), __uint_as_float(t1.y) };
+            const F3 e1{ __uint_as_float(t1.z), __uint_as_float(t1.w), __uint_as_float(t2.x) };
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(h[k] & ~occ);
+            bool t = mine && triHit(r, v0, e0, e1);
+            if (__builtin_amdgcn_ballot_w64(t) != 0) {
+                t = t && boxHit<true>(r, pl[6 * k], pl[6 * k + 1], pl[6 * k + 2], pl[6 * k + 3], pl[6 * k + 4], pl[6 * k + 5]);
+                const uint64_t fresh = __builtin_amdgcn_ballot_w64(t);
+                if (fresh) { occ |= fresh; team.publish(fresh); }
+            }
+        }
+        uint32_t candRef = 0;
+        uint64_t candM = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const uint64_t m = h[k] & ~occ;
+            if (m == 0 || (ref[k] & 1u)) continue;
+            if (candM != 0) push(candRef, candM);
+            candRef = ref[k]; candM = m;
+        }
+        if (candM != 0) { curRef = candRef; curM = candM; have = true; }
+    }
+    if (!dissolve) return occ;
+    // lane per ray from here: every ray from the lowest node it is pending on, but not before a, and not beyond b
+    uint32_t start = END;
+    for (uint32_t e = 0; e < sp; ++e) {
+        const uint64_t m = entryMask(e) & ~occ;
+        if (m == 0) continue;
+        const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)stRef, (int)e);
+        const uint32_t self = *(ConstU32Ptr)(uintptr_t)(wideAddr + eref + 112u);
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) start = self < start ? self : start;
+    }
+    if (start != END && start < a) start = a;
+    const bool h = traverseShare<true, true, true>(bvh, r, start != END, start, lds, nullptr, p.parents, b, &team);
+    return occ | __builtin_amdgcn_ballot_w64(h);
+}
+
+// One piece: the lanes (rays of the tile) it found occluded inside [a, b).
+__device__ __forceinline__ uint64_t traversePiece(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t a, uint32_t b,
+                                                  PieceShare& team, uint32_t* lds) {
+    const uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);
+    if (liveMask == 0) return 0;
+    const u32x8 root = *(ConstNodePtr)(uintptr_t)uniform64(p.bvh);
+    const float rootLo[3] = { __uint_as_float(root.s0), __uint_as_float(root.s1), __uint_as_float(root.s2) };
+    const float rootHi[3] = { __uint_as_float(root.s4), __uint_as_float(root.s5), __uint_as_float(root.s6) };
+    WideRay w;
+    const bool ok = wideRaySetup(r, rootLo, rootHi, w) && raySafe(r);
+    if (__builtin_amdgcn_ballot_w64(live && !ok) != 0) {                 // the same decision in every piece of the tile
+        if (a != 0u) return 0;
+        return __builtin_amdgcn_ballot_w64(traverseShare<false>(bvh, r, live, 0u, lds));
+    }
+    return wideWalkRange(p, bvh, r, w, liveMask, a, b, team, lds);
+}
+
 template <int VARIANT, bool FAST>
 __device__ __forceinline__ bool traverse(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t* lds) {
     if (VARIANT == V_SHARE) return traverseShare<FAST>(bvh, r, live, 0u, lds);
@@ -1028,7 +1216,11 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
 // BANDS (with PLAIN): the everyday launch of ONE STRIPE of a frame cut into interleaved bands (multi-GPU):
 // a band is 2^bandShift tile rows, so the frame row of a tile row is two shifts and a multiply on the scalar unit
 // instead of the general prologue with its per-lane division.
-template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false>
+// TILESPLIT (with PLAIN, one sample): the launch carries a split table (rts_ctx_plan_splits).  The first pieceRows rows of the
+// grid are PIECES of the tiles measured to be long (traversePiece; dispatched first, so the longest work starts first); the
+// remaining rows are the everyday tile waves, of which those of a split tile end after one bitmap look-up.
+template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false,
+          bool TILESPLIT = false>
 // (Registers: a SIMD holds 8 waves of a kernel only up to 64 VGPRs AND 80 SGPRs including VCC / FLAT_SCRATCH / XNACK: the
 //  next granule, 96, plus the 16 the trap handler adds per wave fits 800 only 7 times -- measured with the hardware slot ids
 //  of the probe waves, DESIGN.md 4.7.  Every K = 1 instantiation is inside both limits; tools/gen_wide_asm.py budgets for it.)
@@ -1036,6 +1228,7 @@ __global__ __launch_bounds__(64 * WPB * SPLIT) __attribute__((amdgpu_waves_per_e
 void shadowMaskPacketKernel(TraceParams p) {
     static_assert(!BANDS || (PLAIN && K == 1 && WPB == 1), "the band form exists for the one-tile everyday launch only");
     static_assert(SPLIT == 1 || (K == 1 && WPB == 1 && SOFT), "samples are split over waves in the one-tile soft-shadow form only");
+    static_assert(!TILESPLIT || (PLAIN && K == 1 && WPB == 1 && !SOFT && SPLIT == 1), "split tiles exist for the one-tile everyday launch only");
     __shared__ uint32_t shareSlots[WPB * SPLIT][64];     // lane numbers exchanged by traverseShare (256 B per wave)
     uint32_t* lds = shareSlots[threadIdx.x >> 6];
     // per-lane stacks of the wide lane walk: 4 KB per wave -- which caps a CU at 28 one-wave workgroups instead of 32, so
@@ -1045,7 +1238,24 @@ void shadowMaskPacketKernel(TraceParams p) {
     uint32_t* laneStack = LANE_STACKS ? laneStacks[threadIdx.x >> 6] : nullptr;
     __shared__ uint32_t partial[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 64 : 1];                          // per-wave counts of unoccluded samples
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
-    uint32_t bx = blockIdx.x, by = dispatchRow(p, blockIdx.y);       // (PLAIN: a 2-D grid, rows in dispatchRow order)
+    uint32_t bx = blockIdx.x, by = 0;
+    bool piece = false;
+    uint32_t pieceA = 0, pieceB = END, pieceSlot = 0, pieceCount = 1, pieceId = 0;
+    if constexpr (TILESPLIT) {
+        if (blockIdx.y < p.pieceRows) {                               // a piece of a split tile
+            pieceId = blockIdx.y * gridDim.x + blockIdx.x;
+            if (pieceId >= p.nPieces) return;
+            const u32x4 rec = *(ConstVec4Ptr)(uintptr_t)(uniform64(p.pieces) + (uint64_t)pieceId * 16u);
+            bx = rec.x & 0xFFFFu; by = rec.x >> 16;
+            pieceA = rec.y; pieceB = rec.z; pieceSlot = rec.w & 0xFFFFFFu; pieceCount = rec.w >> 24;
+            piece = true;
+        } else {
+            by = dispatchRow(p, blockIdx.y - p.pieceRows);
+            const uint32_t tile = by * p.blocksX + bx;
+            const uint32_t word = *(ConstU32Ptr)(uintptr_t)(uniform64(p.skipMap) + (uint64_t)(tile >> 5) * 4u);
+            if ((word >> (tile & 31u)) & 1u) return;                   // walked by its pieces
+        }
+    } else by = dispatchRow(p, blockIdx.y);                           // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x0 = WPB == 4 ? bx * (2u * TW) + (wave & 1u) * TW + (lane & 7u) : bx * TW + (lane & 7u);     // (SPLIT: every wave, the same tile)
@@ -1073,12 +1283,46 @@ void shadowMaskPacketKernel(TraceParams p) {
     const uint32_t ns = SOFT ? p.nsamples : 1u;
     // clock probe (every instantiation, so that the clock is measured on the launches that are timed): one wave per tile row
     // (the stamps go straight to memory: nothing of the probe stays in registers across the walk)
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-        uint64_t* o = p.clockProbe + (size_t)(p.grid2d ? blockIdx.y : 0u) * 4;
+    const uint32_t probeRow = TILESPLIT ? blockIdx.y - p.pieceRows : (p.grid2d ? blockIdx.y : 0u);
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && !piece) {
+        uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
     }
     const uint64_t tStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
     const uint64_t rStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memrealtime() : 0;
+    if constexpr (TILESPLIT) {
+        if (piece) {
+            PieceShare team;
+            team.state = p.tileState + (size_t)pieceSlot * 2u;
+            if (p.pieceLog) { team.log = p.pieceLog + (size_t)pieceId * (p.pieceLogCap + 1u); team.logCap = p.pieceLogCap; }
+            const Ray r = makeShadowRay(p, rel[0], 0u, (uint32_t)pix[0]);
+            const uint64_t occ = traversePiece(p, bvh, r, live[0], pieceA, pieceB, team, lds);
+            if (team.log && lane == 0) team.log[0] = team.logCount < team.logCap ? team.logCount : team.logCap;
+            // The piece that finishes last stores the tile.  Both atomics return a value, and the count is only added once
+            // the OR has been performed (its result is an operand of the add as far as the compiler can tell), so the piece
+            // that reads pieceCount - 1 finds every other piece's lanes in state[0].
+            uint32_t done = 0;
+            if (lane == 0) {
+                const uint64_t before = __hip_atomic_fetch_or(team.state, occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint64_t one = 1;
+                asm volatile("; the count follows the OR" : "+v"(one) : "v"(before));
+                done = (uint32_t)__hip_atomic_fetch_add(team.state + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
+            if (done + 1u != pieceCount) return;
+            uint64_t all = 0;
+            if (lane == 0) {
+                all = __hip_atomic_fetch_or(team.state, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint64_t zero = 0;
+                asm volatile("; the reset follows the read" : "+v"(zero) : "v"(all));
+                __hip_atomic_store(team.state, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(team.state + 1, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            all = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(all >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)all);
+            if (live[0]) __builtin_nontemporal_store((uint8_t)(((all >> lane) & 1ull) ? 0u : 1u), &p.mask[pix[0]]);   // comp:148-150
+            return;
+        }
+    }
     int32_t left = 0;
     ShareDiag shareDiag;
     shareDiag.on = !PLAIN && p.waveStats != nullptr;
@@ -1116,8 +1360,8 @@ void shadowMaskPacketKernel(TraceParams p) {
         for (int k = 0; k < K; ++k)
             if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
     }
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-        uint64_t* o = p.clockProbe + (size_t)(p.grid2d ? blockIdx.y : 0u) * 4;
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && !piece) {
+        uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         // (the wave's hardware slot rides in the top 16 bits of the end stamp: 2^48 shader clocks are 32 hours)
@@ -1206,7 +1450,7 @@ void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* block
 
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad) {
     dim3 grid(p.gridBlocks), block(256);
-    if (p.grid2d) grid = dim3(p.blocksX, p.blocksY);
+    if (p.grid2d) grid = dim3(p.blocksX, p.blocksY + (p.pieces ? p.pieceRows : 0u));   // (the pieces of split tiles come first)
     const bool soft = p.nsamples > 1;
     if (variant == V_WIDE && wavesPerBlock == 4) {                       // 2 x 2 tiles per workgroup: neighbours share the scalar cache
         if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, true, false, 1>), grid, block, 0, stream, p);
@@ -1219,6 +1463,10 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
         else if (p.wideLane)                        // lane-per-ray continuation over the wide nodes: the instantiation with LDS stacks
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 3>), grid, b1, ldsPad, stream, p);
+        else if (p.pieces && p.nStripes > 1)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true, true>), grid, b1, ldsPad, stream, p);
+        else if (p.pieces)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, false, true>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
@@ -1238,6 +1486,10 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         case V_PACKET:
             if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 0, 4>), grid, dim3(256), 0, stream, p);
             else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
+            else if (p.pieces && p.nStripes > 1)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true, true>), grid, b1, ldsPad, stream, p);
+            else if (p.pieces)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, false, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
@@ -1262,6 +1514,75 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
     case V_PACKET_PF: if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, true, false>), grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// split planning: visit logs -> piece table.  One workgroup per selected tile: the S - 1 cuts of its index range are the
+// j/S quantiles of the node indices its planning walk logged (a histogram of 1024 bins over the value range, refined inside
+// the bin that holds the quantile until a bin is one index wide).  Piece j of the tile is [cut_j, cut_j+1), cut_0 = 0,
+// cut_S = END; a tile whose log is empty gets one piece that covers everything and S - 1 empty ones.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitQuantilesKernel(const uint32_t* log, uint32_t cap, const SplitCut* cuts, const uint32_t* firstPiece,
+                                                            uint32_t tiles, uint32_t* pieces) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t box[4];                       // [0] min, [1] max, then the refinement's {lo, hi}
+    __shared__ uint32_t below;
+    const uint32_t t = blockIdx.x;
+    if (t >= tiles) return;
+    const uint32_t* L = log + (size_t)t * (cap + 1u);
+    const uint32_t n = L[0] < cap ? L[0] : cap, S = cuts[t].pieces, base = firstPiece[t];
+    if (threadIdx.x == 0) { box[0] = END; box[1] = 0; }
+    __syncthreads();
+    uint32_t mn = END, mx = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) { const uint32_t v = L[1u + i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    atomicMin(&box[0], mn); atomicMax(&box[1], mx);
+    __syncthreads();
+    mn = box[0]; mx = box[1];
+    uint32_t prevCut = 0;
+    for (uint32_t j = 0; j < S; ++j) {
+        uint32_t cut = END;                                             // the end of piece j
+        if (j + 1 < S && n != 0) {
+            const uint32_t target = (uint32_t)(((uint64_t)(j + 1) * n) / S);
+            __syncthreads();
+            if (threadIdx.x == 0) { box[2] = mn; box[3] = mx; below = 0; }
+            for (;;) {
+                __syncthreads();
+                const uint32_t lo = box[2], hi = box[3];
+                const uint32_t width = (uint32_t)(((uint64_t)(hi - lo) + 1024ull) / 1024ull);      // >= 1
+                for (uint32_t i = threadIdx.x; i < 1024; i += 256) hist[i] = 0;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                    const uint32_t v = L[1u + i];
+                    if (v >= lo && v <= hi) atomicAdd(&hist[(v - lo) / width], 1u);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t cum = below, bin = 0;
+                    while (bin < 1023 && cum + hist[bin] <= target) { cum += hist[bin]; ++bin; }
+                    below = cum;
+                    box[2] = lo + bin * width;
+                    const uint64_t top = (uint64_t)lo + (uint64_t)(bin + 1) * width - 1ull;
+                    box[3] = top < hi ? (uint32_t)top : hi;
+                }
+                __syncthreads();
+                if (width == 1) break;
+            }
+            cut = box[2];
+        }
+        if (cut < prevCut) cut = prevCut;
+        if (threadIdx.x == 0) {
+            uint32_t* o = pieces + (size_t)(base + j) * 4u;
+            o[0] = cuts[t].tile; o[1] = prevCut; o[2] = cut; o[3] = t | (S << 24);
+        }
+        prevCut = cut;
+    }
+}
+
+hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const SplitCut* d_cuts, const uint32_t* d_firstPiece,
+                                uint32_t tiles, uint32_t* d_pieces, hipStream_t stream) {
+    if (tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(splitQuantilesKernel, dim3(tiles), dim3(256), 0, stream, d_log, logCap, d_cuts, d_firstPiece, tiles, d_pieces);
     return hipGetLastError();
 }
 

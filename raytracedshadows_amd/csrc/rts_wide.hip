@@ -22,7 +22,9 @@
 //   [24 + k]      slot k: byte offset of the child's wide node (low bit 0) | byte offset of the leaf's triangle
 //                 record + 1 (low bit 1) | 0xFFFFFFFF (empty)
 //   [28]          node index of n in the stream (where a dissolved packet's rays continue the reference's walk)
-//   [29..31]      0
+//   [28 + k]      k = 1..3: node index in the stream of slot k's node (END: empty slot).  Slot k's subtree is the index
+//                 range [index of slot k, index of slot k + 1) -- what the split-tile pieces (rts_kernels.hip) filter on;
+//                 the everyday loops load dwords 0..27 only
 // Slots are in the stream's (depth-first) order, and so are the wide nodes themselves: a subtree is one contiguous range.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,8 +49,10 @@ __device__ __forceinline__ bool finiteBits(uint32_t u) { return (u & 0x7F800000u
 
 // One thread per node, then one per tail vec4.  bad[0] bit 0: structure (the rules of rts_bvh_validate), bit 1: a
 // non-finite float, bit 2: an inner node with bboxMin > bboxMax, bit 3: not a pre-order binary tree with the reference's
-// miss links (right child = link of the left child, link of the right child = link of the parent) or a box that does not
-// enclose its inner children's boxes.
+// miss links (right child = link of the left child, link of the right child = link of the parent, a leaf's link = the node
+// after it -- END only for the last node --, the root's link = END) or a box that does not enclose its inner children's
+// boxes.  With bit 3 clear every node lies in the tree: by induction over link(i) - i the subtree of node i is exactly
+// [i, link(i)), so the root's is [0, N) -- no orphan node exists whose parent entry nobody writes (parentKernel).
 __global__ void validateKernel(StreamView s, uint32_t* bad) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t flags = 0;
@@ -58,6 +62,8 @@ __global__ void validateKernel(StreamView s, uint32_t* bad) {
         for (int k = 0; k < 3; ++k) if (!finiteBits(a[k]) || !finiteBits(a[4 + k])) flags |= 2u;
         const uint32_t next = a[7];
         if (next != END && !(next > i && next < s.N)) flags |= 1u;
+        if (i == 0 && next != END) flags |= 8u;
+        if (a[3] != END && next != (i + 1 < s.N ? i + 1 : END)) flags |= 8u;
         if (a[3] == END) {
             if (i + 1 >= s.N) flags |= 1u;
             else {
@@ -175,39 +181,43 @@ __global__ void emitWideKernel(StreamView s, const uint32_t* parents, const uint
         o[3] = a[0]; o[4] = a[1]; o[5] = a[2];
         o[6] = a[4]; o[7] = a[5]; o[8] = a[6];
         o[9] = n;
-        const uint32_t* pb = s.w + (size_t)parents[n] * 8;          // (P >= 2: every leaf has a parent)
+        if (parents[n] == END) return;                              // (P >= 2 and a validated stream: every leaf has a parent)
+        const uint32_t* pb = s.w + (size_t)parents[n] * 8;
         o[10] = pb[0]; o[11] = pb[1]; o[12] = pb[2];
         o[13] = pb[4]; o[14] = pb[5]; o[15] = pb[6];
         return;
     }
     if (!(counts[n] >> 32)) return;                                  // an inner node of odd depth: folded into its parent
+    if (n != 0 && parents[n] == END) return;                         // (cannot happen for a stream that passed validateKernel)
     uint32_t* o = wide + (size_t)(uint32_t)(rank[n] >> 32) * 32;
     uint32_t k = 0;
-    auto put = [&](uint32_t boxNode, uint32_t ref) {
+    auto put = [&](uint32_t boxNode, uint32_t ref, uint32_t node) {
         const uint32_t* b = s.w + (size_t)boxNode * 8;
         o[6 * k + 0] = b[0]; o[6 * k + 1] = b[1]; o[6 * k + 2] = b[2];
         o[6 * k + 3] = b[4]; o[6 * k + 4] = b[5]; o[6 * k + 5] = b[6];
         o[24 + k] = ref;
+        if (k) o[28 + k] = node;                                     // (slot 0 starts at n + 1 or n + 2)
         ++k;
     };
     auto leafRef = [&](uint32_t c) { return (uint32_t)rank[c] * 64u + 1u; };
     const uint32_t left = n + 1, right = s.link(left);
     const uint32_t kids[2] = { left, right };
     for (uint32_t c : kids) {
-        if (s.leaf(c)) { put(n, leafRef(c)); continue; }
+        if (s.leaf(c)) { put(n, leafRef(c), c); continue; }
         const uint32_t gl = c + 1, gr = s.link(gl);
         const uint32_t grand[2] = { gl, gr };
         for (uint32_t g : grand) {
-            if (s.leaf(g)) put(c, leafRef(g));
-            else put(g, (uint32_t)(rank[g] >> 32) * 128u);
+            if (s.leaf(g)) put(c, leafRef(g), g);
+            else put(g, (uint32_t)(rank[g] >> 32) * 128u, g);
         }
     }
     for (; k < 4; ++k) {
         o[6 * k + 0] = o[6 * k + 1] = o[6 * k + 2] = __float_as_uint(FLT_MAX);
         o[6 * k + 3] = o[6 * k + 4] = o[6 * k + 5] = __float_as_uint(-FLT_MAX);
         o[24 + k] = END;
+        o[28 + k] = END;
     }
-    o[28] = n; o[29] = 0; o[30] = 0; o[31] = 0;
+    o[28] = n;
 }
 
 } // namespace
@@ -248,6 +258,8 @@ hipError_t buildWideDevice(const void* d_packed, uint32_t P, void* d_wide, void*
     hipError_t e = hipMemset(grand, 0, 64);
     if (e != hipSuccess) return e;
     const dim3 block(256), gridN((N + 255) / 256);
+    e = hipMemsetAsync(d_parents, 0xFF, (size_t)N * 4, nullptr);     // END everywhere: no stale entry of a previous stream survives
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(parentKernel, gridN, block, 0, nullptr, s, (uint32_t*)d_parents);
     hipLaunchKernelGGL(classifyKernel, gridN, block, 0, nullptr, s, (const uint32_t*)d_parents, maxDepth, counts, stats);
     hipLaunchKernelGGL(scanTileSums, dim3(tiles), block, 0, nullptr, counts, N, tileSums);

@@ -1,0 +1,74 @@
+"""Experiment (GPU box): split tables (rts_ctx_plan_splits) against the plain launch, same process, same clocks.
+For every config and base kernel: the frame without a table, then with tables planned at several (min_life_us, piece_us,
+max_pieces); per point the median / minimum of N launches between HIP events, back-to-back wall time, and the number of mask
+bytes that differ from the oracle's.
+    KERNELS=3,8 PLANS=20:8:8,40:10:8 python tests/experiments/split_ab.py atrium_1080p courtyard_4k city_4k"""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from raytracedshadows_amd import api, workloads
+import oracle as orc
+
+KERNELS = [int(v) for v in os.environ.get("KERNELS", "3,8").split(",")]
+PLANS = [tuple(float(x) for x in pl.split(":")) for pl in os.environ.get("PLANS", "30:10:8,20:6:8,15:5:16").split(",")]
+OPTS = [kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv]
+N = int(os.environ.get("N", 100))
+
+
+def timeit(ctx, go, n):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        for _ in range(10):
+            go()
+        ctx.synchronize()
+    ts = []
+    for _ in range(n):
+        ctx.timer_mark(0); go(); ctx.timer_mark(1)
+        ts.append(ctx.timer_between_ms(0, 1))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        go()
+    ctx.synchronize()
+    return float(np.median(ts)), float(np.min(ts)), (time.perf_counter() - t0) / n * 1e3
+
+
+for cfg in sys.argv[1:] or ["atrium_1080p"]:
+    wl = workloads.prepare_config(cfg, cache=True)
+    W, H = wl.W, wl.H
+    expect = orc.shadow_mask(wl.packed, wl.constants.as_array(), orc.light_from_product(wl.light, wl.constants), wl.positions, W, H)[0]
+    with api.ShadowContext(0) as ctx:
+        ctx.set_bvh(wl.packed)
+        for k_, v_ in OPTS:
+            ctx.set_option(k_, int(v_))
+        d_pos, d_m = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+        ctx.h2d(d_pos, wl.positions)
+
+        def go():
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_m, light=wl.light)
+
+        def check():
+            ctx.h2d(d_m, np.full(W * H, 9, np.uint8))
+            go(); ctx.synchronize()
+            got = np.empty(W * H, np.uint8)
+            ctx.d2h(got, d_m)
+            return int(np.count_nonzero(got != expect.reshape(-1)))
+
+        for k in KERNELS:
+            ctx.set_option("kernel", k)
+            ctx.clear_splits()
+            med, mn, b2b = timeit(ctx, go, N)
+            print(f"{cfg} kernel {k} no table: median {med:.4f} ms, min {mn:.4f}, back to back {b2b:.4f}; {check()} bytes differ ({ctx.last_kernel_name()})", flush=True)
+            for life, piece, maxp in PLANS:
+                t0 = time.perf_counter()
+                tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_m, light=wl.light, min_life_us=life, piece_us=piece, max_pieces=int(maxp))
+                plan_ms = (time.perf_counter() - t0) * 1e3
+                bad = check()
+                med2, mn2, b2b2 = timeit(ctx, go, N)
+                print(f"{cfg} kernel {k} table life>{life:g}us piece {piece:g}us max {int(maxp)}: {tiles} tiles, {pieces} pieces (planned in {plan_ms:.0f} ms): "
+                      f"median {med2:.4f} ms ({(med2 / med - 1) * 100:+.1f} %), min {mn2:.4f}, back to back {b2b2:.4f}; {bad} bytes differ", flush=True)
+            ctx.clear_splits()
+        ctx.free(d_pos); ctx.free(d_m)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+import streams
 from raytracedshadows_amd import api, partition, scenes, workloads
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +41,28 @@ def _check_workload(ctx, wl, variants=None, swizzles=(0,)):
             assert bad == 0, f"kernel {v} swizzle {sw}: {bad}/{want.size} bytes differ"
     ctx.set_option("xcd_swizzle", 0)
     return want
+
+
+def _striped_frames(ctx, wl, want, d_pos, d_mask, counts=(2, 4, 8), name=None, band=32):
+    """The frame as `n` row stripes -- contiguous [row_begin, row_end) and interleaved `band`-row bands in ONE dispatch per
+    stripe (what rank r of `bench.py --gpus n` launches) -- traced one after the other into one pre-filled mask."""
+    W, H = wl.W, wl.H
+    for n in counts:
+        for interleaved in (False, True):
+            got = np.full((H, W), 9, np.uint8)
+            ctx.h2d(d_mask, got)
+            for r in range(n):
+                if interleaved:
+                    ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, band, n, r, light=wl.light)
+                else:
+                    for b, e in partition.stripe_rows(H, n, r, band=band, interleaved=False):
+                        ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light, row_begin=b, row_end=e)
+                if name is not None:
+                    assert ctx.last_kernel_name() == name, (ctx.last_kernel_name(), name)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            bad = int((got != want).sum())
+            assert bad == 0, f"{name}: {n} stripes, interleaved={interleaved}: {bad} bytes differ"
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "terrain_96"])
@@ -91,31 +114,27 @@ def test_reference_directional_light_city_4k_full_size(ctx, city4k):
     RayTracedShadows.cpp:245) -- at the headline size: the default kernel, the plain loop and the packet kernels."""
     wl = workloads.relight(city4k, "directional")
     assert wl.light is None                                                       # nothing but RayTracingConstants.lightDirection
-    want = _check_workload(ctx, wl, variants=[-1, 0, 3, 4, 7])
+    want = _check_workload(ctx, wl, variants=[-1, 0, 3, 4, 7, 8])             # (8: what bench.py times `city_4k_directional` with)
     assert 0.1 < want.mean() < 0.9
 
 
 def test_config2_courtyard_4k_full_size_hard_scene(ctx):
     """BASELINE configs[2] on the San-Miguel-class stand-in (arcades, nine trees of ~400 000 leaf cards, furniture;
     999 990 triangles): ~60 nodes per ray, rays that scatter between leaves -- packets dissolve, waves run long.
-    Every kernel variant at 3840x2160, then 2- and 8-way interleaved stripes with the default kernel."""
+    Every kernel variant at 3840x2160, then 2/4/8 contiguous and interleaved stripes with the default and both wide kernels."""
     wl = workloads.prepare_config("courtyard_4k")
     want = _check_workload(ctx, wl)
     assert 0.2 < want.mean() < 0.8
     W, H = wl.W, wl.H
-    ctx.set_option("kernel", -1)
     d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
     try:
         ctx.h2d(d_pos, wl.positions)
-        for n in (2, 8):
-            got = np.full((H, W), 9, np.uint8)
-            ctx.h2d(d_mask, got)
-            for r in range(n):
-                ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, r, light=wl.light)
-            ctx.synchronize()
-            ctx.d2h(got, d_mask)
-            assert (got == want).all(), n
+        for kernel, name in ((-1, "shadowMaskPacketKernel<1>"), (8, "shadowMaskPacketKernel<1,wide>"),
+                             (9, "shadowMaskPacketKernel<1,wide,compiled>")):
+            ctx.set_option("kernel", kernel)
+            _striped_frames(ctx, wl, want, d_pos, d_mask, name=name)
     finally:
+        ctx.set_option("kernel", -1)
         ctx.free(d_pos)
         ctx.free(d_mask)
 
@@ -140,26 +159,16 @@ def test_config3_city_4k_row_striped_2_4_8(ctx, city4k):
     the other on this device into one mask (RayTracedShadows.comp:128-151 restricted to the owned rows)."""
     wl, W, H = city4k, city4k.W, city4k.H
     ctx.set_bvh(wl.packed)
-    ctx.set_option("kernel", -1)
     d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
     try:
         ctx.h2d(d_pos, wl.positions)
-        for n in (2, 4, 8):
-            for interleaved in (False, True):
-                got = np.full((H, W), 9, np.uint8)
-                ctx.h2d(d_mask, got)
-                for r in range(n):
-                    if interleaved:
-                        ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, n, r, light=wl.light)
-                    else:
-                        for b, e in partition.stripe_rows(H, n, r, band=32, interleaved=False):
-                            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light,
-                                                         row_begin=b, row_end=e)
-                    assert ctx.last_kernel_name() == "shadowMaskPacketKernel<1>"
-                ctx.synchronize()
-                ctx.d2h(got, d_mask)
-                bad = int((got != wl.want).sum())
-                assert bad == 0, f"{n} stripes, interleaved={interleaved}: {bad} bytes differ"
+        # the default kernel, and the two wide kernels -- 8 is what `bench.py --gpus N` autotunes to on this frame, and a striped
+        # dispatch of it runs the BANDS instantiation (rts_kernels.hip: launchShadowMask)
+        for kernel, name in ((-1, "shadowMaskPacketKernel<1>"), (8, "shadowMaskPacketKernel<1,wide>"),
+                             (9, "shadowMaskPacketKernel<1,wide,compiled>")):
+            ctx.set_option("kernel", kernel)
+            _striped_frames(ctx, wl, wl.want, d_pos, d_mask, name=name)
+        ctx.set_option("kernel", -1)
         # one stripe of an 8-way partition touches only its own rows
         got = np.full((H, W), 9, np.uint8)
         ctx.h2d(d_mask, got)
@@ -178,9 +187,20 @@ def test_config4_city_4k_16_samples_full_size(ctx, city4k):
     scene with the kernel bench.py uses (AUTO = the SOFT instantiation of the packet kernel) and packet variants 3-5;
     the byte is the number of unoccluded samples."""
     wl = workloads.relight(city4k, "point", 16)
-    want = _check_workload(ctx, wl, variants=[-1, 3, 4, 5])
+    want = _check_workload(ctx, wl, variants=[-1, 3, 4, 5, 8])
     assert want.max() == 16 and (want == 0).any() and ((want > 0) & (want < 16)).sum() > 10000   # penumbrae exist
-    ctx.set_option("kernel", -1)
+    # ... and striped (configs[3] x configs[4]): the wide kernel with 4 waves per tile ("soft_split"), contiguous and interleaved
+    W, H = wl.W, wl.H
+    ctx.set_option("kernel", 8)
+    ctx.set_option("soft_split", 1)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        _striped_frames(ctx, wl, want, d_pos, d_mask, counts=(4, 8), name="shadowMaskPacketKernel<1,wide>")
+    finally:
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+        ctx.set_option("kernel", -1)
 
 
 def test_config4_per_pixel_jitter_every_kernel_and_stripes(ctx):
@@ -358,6 +378,125 @@ def test_degenerate_and_denormal_triangles(ctx):
         ctx.set_option("kernel", v)
         got = ctx.trace_rays(rays)
         assert (got == want).all(), f"kernel {v}: {(got != want).sum()} rays differ"
+
+
+def _deep_bushy_stream(levels):
+    """A tree whose wide walk keeps three subtrees pending per level: node(l) = ((node(l-1), small), (small, small)), small =
+    two tiny triangles in opposite corners of the unit square (its box covers the middle, where every ray passes; the
+    triangles are hit by nobody).  Level 0 holds two real occluders."""
+    tris, z = [], [0.0]
+
+    def tiny(x, y):
+        tris.append([[x, y, z[0]], [x + 1e-3, y, z[0]], [x, y + 1e-3, z[0]]])
+        return len(tris) - 1
+
+    def small():
+        z[0] += 0.25
+        a = tiny(0.05, 0.05)
+        z[0] += 0.25
+        return (a, tiny(0.95, 0.95))
+
+    def node(l):
+        if l == 0:
+            z[0] += 0.5
+            tris.append([[0.0, 0.0, z[0]], [0.55, 0.0, z[0]], [0.0, 0.9, z[0]]])          # occludes the rays of one corner
+            tris.append([[0.6, 0.6, z[0] + 0.1], [0.9, 0.6, z[0] + 0.1], [0.6, 0.9, z[0] + 0.1]])
+            return (len(tris) - 2, len(tris) - 1)
+        return ((node(l - 1), small()), (small(), small()))
+
+    tree = node(levels)
+    return streams.stream_from_tree(tree, np.array(tris, np.float32))
+
+
+def test_wide_stack_limit_dissolves_and_keeps_every_pixel(ctx):
+    """the wide packet's stack lives in lanes 0..62 of three VGPRs and lane 63 keeps EXEC of the entry; a walk
+    that pushes three subtrees per level for 25 levels must dissolve BEFORE entry 63 is written, and every pixel of the tile
+    must still be traversed and stored.  packet_share = 0 switches the coherence rule off, so the stack limit is the only way
+    to dissolve -- the wave statistics must show that it did."""
+    packed = _deep_bushy_stream(25)
+    assert api.bvh_validate(packed) == (packed.shape[0] + 2) // 5
+    W = H = 24
+    pos = np.zeros((H, W, 4), np.float32)
+    pos[..., 0] = 0.2 + 0.6 * (np.arange(W, dtype=np.float32)[None, :] + 0.5) / W
+    pos[..., 1] = 0.2 + 0.6 * (np.arange(H, dtype=np.float32)[:, None] + 0.5) / H
+    k = api.RayTracingConstants.make([0, 0, 0], [0.001, 0.002, 1.0], W, H)
+    want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(None, k), pos, W, H)
+    assert 0 < want.sum() < want.size
+    ctx.set_bvh(packed)
+    assert ctx.get_option("wide_nodes") > 25
+    waves = (W // 8) * (H // 8)
+    d_pos, d_mask = ctx.malloc(pos.nbytes), ctx.malloc(W * H)
+    ctx.h2d(d_pos, pos)
+
+    def trace():                                    # device pointers and a pre-filled mask: a pixel nobody stores shows
+        got = np.full((H, W), 9, np.uint8)
+        ctx.h2d(d_mask, got)
+        ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask)
+        ctx.synchronize()
+        ctx.d2h(got, d_mask)
+        return got
+
+    try:
+        ctx.set_option("packet_share", 0)
+        for kernel in (8, 9):
+            for lane in (0, 1):
+                ctx.set_option("kernel", kernel)
+                ctx.set_option("wide_lane", lane)
+                got = trace()
+                assert (got == want).all(), (kernel, lane, int((got != want).sum()))
+                ctx.set_option("wave_stats", waves)
+                got = trace()
+                st = ctx.read_wave_stats(waves)
+                ctx.set_option("wave_stats", 0)
+                assert (got == want).all(), (kernel, lane, "with wave statistics")
+                assert (st[:, 2] & 1).all(), "every tile's packet must have run into the stack limit and dissolved"
+        ctx.set_option("packet_share", 4)
+        for kernel in _variants(ctx):                                   # and the stream as such, every kernel
+            ctx.set_option("kernel", kernel)
+            assert (trace() == want).all(), kernel
+    finally:
+        for key, v in (("kernel", -1), ("packet_share", 4), ("wide_lane", 0), ("wave_stats", 0)):
+            ctx.set_option(key, v)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
+def test_stream_with_orphan_nodes_gets_no_private_copy(ctx):
+    """rts_bvh_validate accepts a stream in which a leaf's miss link skips nodes (the skipped nodes are
+    orphans no walk ever reaches).  The device-side verdict must then say "not a pre-order tree" so that no wide copy is
+    derived from parent entries nobody wrote; every kernel still equals the oracle on that very stream."""
+    tris = np.zeros((3, 3, 3), np.float32)
+    tris[0] = [[0, 0, 5], [4, 0, 5], [0, 4, 5]]
+    tris[1] = [[6, 6, 7], [9, 6, 7], [6, 9, 7]]
+    tris[2] = [[2, 2, 3], [3, 2, 3], [2, 3, 3]]                       # only the stray leaves point at it
+    good = streams.stream_from_tree(((0, 1), 2), tris)                # N = 5: 0 inner, 1 inner, 2 leaf, 3 leaf, 4 leaf
+    N = 5
+    bad = good.copy()
+    # root 0 -> children: leaf 1 (link 4) and leaf 4; nodes 2 and 3 are stray leaves
+    f = bad.view(np.float32)
+    f[2, :3] = tris[0, 1] - tris[0, 0]; bad[2, 3] = 2 * N + 0
+    f[3, :3] = tris[0, 2] - tris[0, 0]; bad[3, 3] = 4
+    for i in (2, 3):
+        f[2 * i, :3] = tris[2, 1] - tris[2, 0]; bad[2 * i, 3] = 2 * N + 2
+        f[2 * i + 1, :3] = tris[2, 2] - tris[2, 0]; bad[2 * i + 1, 3] = i + 1
+    f[8, :3] = tris[1, 1] - tris[1, 0]; bad[8, 3] = 2 * N + 1
+    f[9, :3] = tris[1, 2] - tris[1, 0]; bad[9, 3] = 0xFFFFFFFF
+    assert api.bvh_validate(bad) == 3
+    W, H = 64, 64
+    pos = np.zeros((H, W, 4), np.float32)
+    pos[..., 0] = 10.0 * (np.arange(W, dtype=np.float32)[None, :] + 0.5) / W
+    pos[..., 1] = 10.0 * (np.arange(H, dtype=np.float32)[:, None] + 0.5) / H
+    k = api.RayTracingConstants.make([0, 0, 0], [0.001, 0.002, 1.0], W, H)
+    for blob, enclosed in ((good, 1), (bad, 0)):
+        want, _, _ = oracle.shadow_mask(blob, k.as_array(), oracle.light_from_product(None, k), pos, W, H)
+        assert 0 < want.sum() < want.size
+        ctx.set_bvh(blob)
+        assert ctx.get_option("bvh_enclosed") == enclosed
+        assert (ctx.get_option("wide_nodes") > 0) == bool(enclosed)
+        for v in _variants(ctx):
+            ctx.set_option("kernel", v)
+            assert (ctx.trace_shadow_mask(k, pos, W, H) == want).all(), (enclosed, v)
+    ctx.set_option("kernel", -1)
 
 
 def test_non_finite_bvh_takes_the_exact_path(ctx):
@@ -728,6 +867,7 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
               api.Light.make(api.Light.POINT, hi + 5, scenes.jitter_offsets(int(rs.randint(9, 65)), 0.7, seed),
                              nsamples=int(rs.randint(2, 9)))]                                                  # per-pixel jitter
     ctx.set_bvh(packed)
+    d_pos, d_mask = ctx.malloc(pos.nbytes), ctx.malloc(W * H)
     try:
         for light in lights:
             want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(light, k), pos, W, H)
@@ -741,9 +881,26 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                 got = ctx.trace_shadow_mask(k, pos, W, H, light=light)
                 bad = int((got != want).sum())
                 assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
+                # ... and as row stripes (contiguous through the host-pointer entry; 32-row interleaved bands in one dispatch)
+                ns = int(rs.randint(2, 5))
+                got = np.full((H, W), 9, np.uint8)
+                for r in range(ns):
+                    for b, e in partition.stripe_rows(H, ns, r, 32, False):
+                        ctx.trace_shadow_mask(k, pos, W, H, light=light, row_begin=b, row_end=e, out=got)
+                assert (got == want).all(), (seed, kernel, "contiguous stripes", ns)
+                got = np.full((H, W), 9, np.uint8)
+                ctx.h2d(d_pos, pos)
+                ctx.h2d(d_mask, got)
+                for r in range(ns):
+                    ctx.trace_shadow_mask_stripes_device(k, d_pos, W, H, d_mask, 32, ns, r, light=light)
+                ctx.synchronize()
+                ctx.d2h(got, d_mask)
+                assert (got == want).all(), (seed, kernel, "interleaved stripes", ns)
     finally:
-        for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("wide_lane", 1), ("soft_split", 1)):
+        for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("wide_lane", 0), ("soft_split", 1)):
             ctx.set_option(key, v)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
 
 
 def test_plain_c_caller_of_the_consumer_seam(tmp_path):

@@ -20,7 +20,9 @@ Fixed scratch SGPRs (declared as clobbers), relative to SGPR_BASE = 20 -- 54 of 
     H0..H3    +38..+45  members that hit slot k          M   +46,47  members of the current node
     NXM       +48,49    members of the next node        NXREF +50   its ref (-1: none yet)
     REF       +51       byte offset of the current node  R   +52,53  reject mask / temporaries (the second temporary mask is VCC)
-EXEC at entry is kept in lane 63 of the stack's two mask registers (the stack dissolves before entry 61 is written).
+EXEC at entry is kept in lane 63 of the stack's two mask registers.  A node is only taken up with at most 59 entries on the
+stack: it pushes at most 3 (62), and the dissolve that follows writes the current node back as entry 62 at the latest, so
+lane 63 is never written by the stack (tests/test_gpu_parity.py: test_wide_stack_limit_dissolves_and_keeps_every_pixel).
 """
 import os
 import sys
@@ -199,7 +201,7 @@ def loop(octant):
          f"s_load_dwordx16 s[{BASE}:{BASE + 15}], %[wb], {REF}",
          f"s_load_dwordx8 s[{BASE + 16}:{BASE + 23}], %[wb], {REF} offset:64",
          f"s_load_dwordx4 s[{BASE + 24}:{BASE + 27}], %[wb], {REF} offset:96",
-         "s_cmp_gt_u32 %[sp], 60",                               # a node pushes at most 3 entries; 64 fit
+         "s_cmp_gt_u32 %[sp], 59",                               # a node pushes at most 3 entries; entry 63 is the saved EXEC
          "s_cbranch_scc1 80f",
          f"s_mov_b32 {NXREF}, -1",
          f"s_mov_b64 exec, {M}",
