@@ -253,11 +253,19 @@ int rts_ctx_read_clock_probe(rts_ctx* ctx, uint64_t* out, size_t rows);
 /* Picks the kernel for this frame by timing the candidates on it (lane-per-ray with work sharing for small frames, the
  * packet kernel, the wide packet kernel) -- what a renderer does once per scene and resolution; then, for a packet kernel,
  * the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile rows are started ("row_order" 0 or 1), each
- * kept only if it gains 1.5 %.  Leaves the options "kernel", "packet_share" and "row_order" set to the winners (*chosen =
- * the kernel, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
- * Results never depend on any of the three. */
+ * kept only if it gains 1.5 %; then a split table (rts_ctx_plan_splits below) for the tiles that lived longer than 15 % / 10 %
+ * of the frame and ended in its second half / last quarter, kept on the same condition (any table installed before is
+ * dropped).  Leaves the options "kernel", "packet_share" and "row_order" set to the winners and the winning table installed
+ * (*chosen = the kernel, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
+ * Results never depend on any of it. */
 int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
                      uint32_t W, uint32_t H, uint8_t* d_mask, int* chosen, float* ms);
+/* The same for the dispatch of rts_trace_shadow_mask_stripes_device with these band_rows / n_stripes / stripe: what rank
+ * `stripe` of an n_stripes-GPU frame launches is what it tunes -- kernel, dissolve threshold, and the split
+ * table for its own rows (one eighth of a 4K frame is two rounds of the chip's wave slots: its time is its longest waves). */
+int rts_ctx_autotune_stripes(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                             uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                             int* chosen, float* ms);
 /* ---- split tiles: the few tiles that are measured to be LONG walked by several waves -------------------------------------
  * The reference maps one 8x8 tile to one 64-thread group (RayTracedShadows.comp:127, dispatch RayTracedShadows.cpp:590-592) and
  * so does every kernel here; a frame's time is then often its few longest waves.  A split table breaks that mapping for
@@ -269,7 +277,8 @@ int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_lig
  * rts_ctx_plan_splits measures and installs the table for ONE dispatch geometry (frame size and row range, or stripe):
  *   1. wave statistics of the dispatch (one launch with "wave_stats"), or the caller's statistics of an EARLIER frame
  *      (prev_stats / prev_realtime as rts_ctx_read_wave_stats / rts_ctx_read_wave_realtime return them, prev_waves entries);
- *   2. the tiles whose wave lived longer than min_life_us (the longest max_tiles of them) are walked once more, alone, with
+ *   2. the tiles whose wave lived longer than min_life_us and ended later than end_after_us (the longest max_tiles of
+ *      them) are walked once more, alone, with
  *      their visited node indices logged; tile t gets S = ceil(life / piece_us) pieces (2 .. max_pieces), its ranges cut at
  *      the j/S quantiles of its log.
  * Every later trace with the same geometry, one sample per pixel and kernel 3 or 8 uses the table (option "tile_splits" 0
@@ -279,6 +288,8 @@ int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_lig
  * device pointers.  Results never depend on any of it (tests/test_gpu_parity.py). */
 typedef struct rts_split_plan {
     float    min_life_us;        /* > 0 */
+    float    end_after_us;       /* >= 0: ... and only the tiles whose wave ENDED later than this after the dispatch's first wave
+                                    started (the waves that end last are the dispatch's tail; 0 = every long tile) */
     float    piece_us;           /* > 0 */
     uint32_t max_pieces;         /* 2..64 */
     uint32_t max_tiles;          /* 0 = 4096 */
@@ -294,6 +305,15 @@ int rts_ctx_plan_splits_stripes(rts_ctx* ctx, const rts_constants* constants, co
                                 uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
                                 const rts_split_plan* plan, uint32_t* tiles, uint32_t* pieces);
 int rts_ctx_clear_splits(rts_ctx* ctx);
+/* The parameters the installed table was planned with (prev_* NULL): what a caller that tunes in one process and renders in
+ * another hands to rts_ctx_plan_splits there.  RTS_ERR_INVALID_ARG without a table. */
+int rts_ctx_get_split_plan(rts_ctx* ctx, rts_split_plan* out);
+/* Diagnostics (tools/piece_stats.py): the first `pieces` records of the installed table -- 8 x u32 {tile x | tile y << 16, first
+ * node, end node, state slot | pieces of the tile << 24, byte offset of the wide node the piece starts at, 0, 0, 0} -- and, after rts_ctx_set_option(ctx, "piece_stats", n), 8 x u64 per
+ * piece of the last launch that used the table: 100 MHz clock at {start, end, rays ready, end of the packet phase, start of the
+ * lane-per-ray phase, end of the walk}, {wide nodes entered | stack entries at the dissolve << 32}, lanes found occluded.
+ * Either pointer may be NULL. */
+int rts_ctx_read_piece_stats(rts_ctx* ctx, uint32_t* records, uint64_t* clocks, size_t pieces);
 /* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks
  * from the wave's start to its first ray being ready (G-buffer texel in, ray set up), XCC id.  With the start/end shader
  * clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */

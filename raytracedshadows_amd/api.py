@@ -155,7 +155,7 @@ _sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 
 class SplitPlan(C.Structure):
     """rts_split_plan (include/rts.h)."""
-    _fields_ = [("min_life_us", C.c_float), ("piece_us", C.c_float), ("max_pieces", C.c_uint32), ("max_tiles", C.c_uint32),
+    _fields_ = [("min_life_us", C.c_float), ("end_after_us", C.c_float), ("piece_us", C.c_float), ("max_pieces", C.c_uint32), ("max_tiles", C.c_uint32),
                 ("prev_stats", C.c_void_p), ("prev_realtime", C.c_void_p), ("prev_waves", C.c_size_t)]
 
 
@@ -164,6 +164,10 @@ _sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants),
 _sig("rts_ctx_plan_splits_stripes", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32,
      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rts_ctx_clear_splits", C.c_int, C.c_void_p)
+_sig("rts_ctx_get_split_plan", C.c_int, C.c_void_p, C.POINTER(SplitPlan))
+_sig("rts_ctx_autotune_stripes", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+     C.c_uint32, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float))
+_sig("rts_ctx_read_piece_stats", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 _sig("rts_timer_mark", C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
 _sig("rts_timer_between_ms", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float))
 _sig("rts_device_mem_info", C.c_int, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
@@ -436,20 +440,34 @@ class ShadowContext:
         _check(_lib.rts_ctx_read_wave_realtime(self._h, _ptr(out), waves), "rts_ctx_read_wave_realtime")
         return out
 
-    def autotune(self, constants, d_positions, width, height, d_mask, light=None):
-        """rts_ctx_autotune: times the candidate kernels on this frame, keeps the fastest; returns (kernel id, ms)."""
+    def autotune(self, constants, d_positions, width, height, d_mask, light=None, stripes=None):
+        """rts_ctx_autotune(_stripes): times the candidate kernels, launch options and split tables on this dispatch (stripes =
+        (band_rows, n_stripes, stripe) for one rank's interleaved stripe), keeps the fastest; returns (kernel id, ms)."""
         chosen, ms = C.c_int(-1), C.c_float(0)
         lp = C.byref(light) if light is not None else None
-        _check(_lib.rts_ctx_autotune(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
-                                     C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)), "rts_ctx_autotune")
+        if stripes is not None:
+            _check(_lib.rts_ctx_autotune_stripes(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height, stripes[0],
+                                                 stripes[1], stripes[2], C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)),
+                   "rts_ctx_autotune_stripes")
+        else:
+            _check(_lib.rts_ctx_autotune(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
+                                         C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)), "rts_ctx_autotune")
         return int(chosen.value), float(ms.value)
 
+    def split_plan(self):
+        """Parameters of the installed split table as a dict (None without a table): rts_ctx_get_split_plan."""
+        plan = SplitPlan()
+        if _lib.rts_ctx_get_split_plan(self._h, C.byref(plan)) != 0:
+            return None
+        return {"min_life_us": float(plan.min_life_us), "end_after_us": float(plan.end_after_us), "piece_us": float(plan.piece_us),
+                "max_pieces": int(plan.max_pieces), "max_tiles": int(plan.max_tiles)}
+
     def plan_splits(self, constants, d_positions, width, height, d_mask, light=None, min_life_us=20.0, piece_us=10.0,
-                    max_pieces=8, max_tiles=0, row_begin=0, row_end=None, stripes=None, prev=None):
+                    max_pieces=8, max_tiles=0, row_begin=0, row_end=None, stripes=None, prev=None, end_after_us=0.0):
         """rts_ctx_plan_splits(_stripes): measures the dispatch, installs the split table; returns (tiles, pieces).
         stripes = (band_rows, n_stripes, stripe) plans the interleaved-stripe dispatch; prev = (stats, realtime) arrays of an
         earlier frame (read_wave_stats / read_wave_realtime) instead of a measuring launch."""
-        plan = SplitPlan(min_life_us, piece_us, max_pieces, max_tiles, None, None, 0)
+        plan = SplitPlan(min_life_us, end_after_us, piece_us, max_pieces, max_tiles, None, None, 0)
         keep = None
         if prev is not None:
             keep = (np.ascontiguousarray(prev[0], np.uint64), np.ascontiguousarray(prev[1], np.uint64))
@@ -466,6 +484,13 @@ class ShadowContext:
                                             row_end, C.c_void_p(d_mask), C.byref(plan), C.byref(tiles), C.byref(pieces)),
                    "rts_ctx_plan_splits")
         return int(tiles.value), int(pieces.value)
+
+    def read_piece_stats(self, pieces, clocks=True):
+        """(records uint32[pieces, 8], clocks uint64[pieces, 8] or None): rts_ctx_read_piece_stats."""
+        rec = np.zeros((pieces, 8), np.uint32)
+        clk = np.zeros((pieces, 8), np.uint64) if clocks else None
+        _check(_lib.rts_ctx_read_piece_stats(self._h, _ptr(rec), _ptr(clk) if clocks else None, pieces), "rts_ctx_read_piece_stats")
+        return rec, clk
 
     def clear_splits(self):
         _check(_lib.rts_ctx_clear_splits(self._h), "rts_ctx_clear_splits")

@@ -54,13 +54,15 @@ struct rts_ctx {
         bool valid = false;
         uint32_t W = 0, H = 0, rowBegin = 0, rowEnd = 0, bandRows = 0, nStripes = 0, stripe = 0, blocksX = 0, blocksY = 0;
         uint32_t* d_skipMap = nullptr;       // one bit per tile of the dispatch
-        uint32_t* d_pieces = nullptr;        // 4 dwords per piece
+        uint32_t* d_pieces = nullptr;        // 8 dwords per piece
         uint32_t nPieces = 0, pieceRows = 0, nTiles = 0;
+        rts_split_plan plan{};               // what the table was planned with (rts_ctx_get_split_plan)
         // {occluded lanes, pieces done} per split tile: one buffer per stream that traces with the table, so that frames in
         // flight on different streams never meet in it (frames on one stream follow each other)
         std::vector<std::pair<void*, uint64_t*>> state;
     } splits;
     int useSplits = 1;                       // option "tile_splits": 0 ignores an installed table
+    uint64_t* d_pieceClock = nullptr; size_t pieceClockCount = 0;    // option "piece_stats"
     struct Planning {                        // set by rts_ctx_plan_splits around its pieces-only launch
         const uint32_t* d_pieces; uint32_t nPieces, pieceRows; uint64_t* d_state; uint32_t* d_log; uint32_t logCap;
     };
@@ -106,7 +108,9 @@ uint64_t* splitState(rts_ctx* c, void* stream) {
     if (t.state.size() >= 8) return nullptr;                       // more streams than that trace without the table
     uint64_t* d = nullptr;
     if (hipMalloc((void**)&d, (size_t)t.nTiles * 16 + 16) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemset(d, 0, (size_t)t.nTiles * 16 + 16) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    // (cleared ON the stream that is about to use it: a memset on the default stream is not ordered before a launch on a
+    //  non-blocking stream)
+    if (hipMemsetAsync(d, 0, (size_t)t.nTiles * 16 + 16, (hipStream_t)stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
     try { t.state.emplace_back(stream, d); } catch (...) { (void)hipFree(d); return nullptr; }
     return d;
 }
@@ -256,6 +260,7 @@ int rts_ctx_destroy(rts_ctx* c) {
     if (c->d_wide) (void)hipFree(c->d_wide);
     if (c->d_word) (void)hipFree(c->d_word);
     if (c->d_clockProbe) (void)hipFree(c->d_clockProbe);
+    if (c->d_pieceClock) (void)hipFree(c->d_pieceClock);
     clearSplits(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -302,6 +307,16 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { c->useSplits = value ? 1 : 0; return RTS_OK; }     // 0: traces ignore an installed split table
+    if (!strcmp(key, "piece_stats")) {          // diagnostics: value = pieces to stamp (0 = off), see rts_ctx_read_piece_stats
+        RTS_HIP(hipSetDevice(c->device));
+        if (c->d_pieceClock) { RTS_HIP(hipFree(c->d_pieceClock)); c->d_pieceClock = nullptr; c->pieceClockCount = 0; }
+        if (value > 0) {
+            RTS_HIP(hipMalloc((void**)&c->d_pieceClock, (size_t)value * 64));
+            RTS_HIP(hipMemset(c->d_pieceClock, 0, (size_t)value * 64));
+            c->pieceClockCount = (size_t)value;
+        }
+        return RTS_OK;
+    }
     if (!strcmp(key, "clock_probe")) {          // value = tile rows to stamp (0 = off); packet kernels on 2-D grids
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_clockProbe) { RTS_HIP(hipFree(c->d_clockProbe)); c->d_clockProbe = nullptr; c->clockProbeRows = 0; }
@@ -439,6 +454,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         if (uint64_t* st = splitState(c, stream)) {
             p.skipMap = sp.d_skipMap; p.pieces = sp.d_pieces; p.nPieces = sp.nPieces; p.pieceRows = sp.pieceRows;
             p.tileState = st;
+            if (c->d_pieceClock && c->pieceClockCount >= sp.nPieces) p.pieceClock = c->d_pieceClock;
         }
     }
     c->lastKernel = rts::kernelName(variant, true);
@@ -689,76 +705,14 @@ int rts_ctx_read_clock_probe(rts_ctx* c, uint64_t* out, size_t rows) {
     return RTS_OK;
 }
 
-// Picks the kernel for THIS frame by timing the candidates on it (what a renderer does once per scene and resolution):
-// the lane-per-ray walk with work sharing, the packet kernel, the wide packet kernel (when the stream has a private copy).
-// Then, for a packet kernel, two launch parameters that are worth 2-6 % on some frames and cost as much on others
-// (profiles/r03/autotune_stage2_sweep.log): the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile
-// rows are started ("row_order" top-down or bottom-up: the rows started last are the kernel's tail).  Leaves the three
-// options set to the winners.  Results never depend on any of them.
-int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W,
-                     uint32_t H, uint8_t* d_mask, int* chosen, float* ms_out) {
-    if (!c || !k || !d_positions || !d_mask) return RTS_ERR_INVALID_ARG;
-    RTS_HIP(hipSetDevice(c->device));
-    int status = RTS_OK;
-    auto median5 = [&](float* out) {          // two untimed launches, then the median of five
-        float times[5];
-        for (int i = -2; i < 5; ++i) {
-            hipError_t e = hipEventRecord(c->ev0, nullptr);
-            if (e != hipSuccess) { status = hipStatus(e); return false; }
-            status = rts_trace_shadow_mask_device(c, k, light, d_positions, W, H, 0, H, d_mask, nullptr);
-            if (status != RTS_OK) return false;
-            float ms = 0;
-            e = hipEventRecord(c->ev1, nullptr);
-            if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            if (e != hipSuccess) { status = hipStatus(e); return false; }
-            if (i >= 0) times[i] = ms;
-        }
-        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
-        *out = times[2];
-        return true;
-    };
-    // (the wide kernel first, and a later candidate must beat the best by 2 %: at equal frame time the wide kernel's waves
-    //  are shorter, which is what a striped multi-GPU frame needs -- tools/stripe_scaling.py)
-    const int candidates[3] = { rts::V_WIDE, rts::V_PACKET, rts::V_SHARE };
-    const int before = c->variant, shareBefore = c->packetShare, orderBefore = c->rowOrder;
-    int best = before;
-    float bestMs = 1e30f;
-    for (int v : candidates) {
-        if (v == rts::V_WIDE && !c->wideCount) continue;
-        if (v == rts::V_SHARE && (uint64_t)W * H > (1u << 20)) continue;        // (never close on a big frame: skip its long launches)
-        c->variant = v;
-        float ms;
-        if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
-        if (ms < bestMs * 0.98f) { bestMs = ms; best = v; }
-    }
-    c->variant = best;
-    if (best == rts::V_WIDE || best == rts::V_PACKET) {
-        // second stage, one parameter at a time; a change must gain 1.5 % to be kept (launch-to-launch noise is below 1 %)
-        float ms;
-        if (c->packetShare == 4) {
-            c->packetShare = 6;
-            if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
-            if (ms < bestMs * 0.985f) bestMs = ms; else c->packetShare = shareBefore;
-        }
-        if (c->rowOrder == 0 && !c->d_tileOrder && !c->swizzle) {
-            c->rowOrder = 1;
-            if (!median5(&ms)) { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; return status; }
-            if (ms < bestMs * 0.985f) bestMs = ms; else c->rowOrder = orderBefore;
-        }
-    }
-    if (chosen) *chosen = best;
-    if (ms_out) *ms_out = bestMs;
-    return RTS_OK;
-}
-
 // Plans the split table for ONE dispatch geometry (see include/rts.h).  Synchronous, default stream.
 static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
                           uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
                           const rts_split_plan* plan, uint32_t* tiles_out, uint32_t* pieces_out) {
     if (tiles_out) *tiles_out = 0;
     if (pieces_out) *pieces_out = 0;
-    if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f)) return RTS_ERR_INVALID_ARG;
+    if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f) || !(plan->end_after_us >= 0.f))
+        return RTS_ERR_INVALID_ARG;
     if (light && light->nsamples > 1) return RTS_ERR_INVALID_ARG;               // (soft shadows are dealt over waves by "soft_split")
     RTS_HIP(hipSetDevice(c->device));
     clearSplits(c);
@@ -806,10 +760,13 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         std::vector<Sel> sel;
         const uint32_t blocksX = (W + 7) / 8;
         uint32_t blocksY = 0;
+        uint64_t began = ~0ull;                                                 // the dispatch's first wave
+        for (size_t i = 0; i < waves; ++i) if (rt[i * 4 + 1] > rt[i * 4] && rt[i * 4] < began) began = rt[i * 4];
         for (size_t i = 0; i < waves; ++i) {
             const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
             if (r1 <= r0) continue;
             const float us = (float)(r1 - r0) * 0.01f;
+            if ((float)(r1 - began) * 0.01f <= plan->end_after_us) continue;
             const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
             if (by >= blocksY) blocksY = by + 1;
             if (us > plan->min_life_us && bx < blocksX) sel.push_back({ us, bx | (by << 16) });
@@ -819,7 +776,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         if (sel.size() > maxTiles) sel.resize(maxTiles);
         const uint32_t T = (uint32_t)sel.size();
         std::vector<rts::SplitCut> cuts(T);
-        std::vector<uint32_t> first(T), provisional((size_t)T * 4);
+        std::vector<uint32_t> first(T), provisional((size_t)T * 8, 0u);
         uint32_t nPieces = 0;
         for (uint32_t t = 0; t < T; ++t) {
             uint32_t S = (uint32_t)std::ceil(sel[t].us / plan->piece_us);
@@ -827,8 +784,8 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             cuts[t] = { sel[t].tile, S };
             first[t] = nPieces;
             nPieces += S;
-            provisional[(size_t)t * 4 + 0] = sel[t].tile; provisional[(size_t)t * 4 + 1] = 0; provisional[(size_t)t * 4 + 2] = 0xFFFFFFFFu;
-            provisional[(size_t)t * 4 + 3] = t | (1u << 24);
+            provisional[(size_t)t * 8 + 0] = sel[t].tile; provisional[(size_t)t * 8 + 1] = 0; provisional[(size_t)t * 8 + 2] = 0xFFFFFFFFu;
+            provisional[(size_t)t * 8 + 3] = t | (1u << 24);                       // (dword 4: the walk starts at the root, offset 0)
         }
         // the dispatch this table belongs to (what traceMaskImpl will compute for the same arguments)
         uint32_t rows = row_end - row_begin;
@@ -845,14 +802,14 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         const size_t logBytes = (size_t)T * (logCap + 1) * 4;
         hipError_t e = hipMalloc(&d_cuts, (size_t)T * 8);
         if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)T * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_prov, (size_t)T * 16);
+        if (e == hipSuccess) e = hipMalloc(&d_prov, (size_t)T * 32);
         if (e == hipSuccess) e = hipMalloc(&d_log, logBytes);
         if (e == hipSuccess) e = hipMalloc(&d_state, (size_t)T * 16);
-        if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)nPieces * 16);
+        if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)nPieces * 32);
         if (e == hipSuccess) e = hipMalloc(&d_map, bitmap.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(d_cuts, cuts.data(), (size_t)T * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_first, first.data(), (size_t)T * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_prov, provisional.data(), (size_t)T * 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_prov, provisional.data(), (size_t)T * 32, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_map, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(d_log, 0, logBytes);
         if (e == hipSuccess) e = hipMemset(d_state, 0, (size_t)T * 16);
@@ -862,7 +819,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
             c->planning = nullptr;
             if (status == RTS_OK) e = rts::launchSplitQuantiles((const uint32_t*)d_log, logCap, (const rts::SplitCut*)d_cuts, (const uint32_t*)d_first,
-                                                                T, (uint32_t*)d_pieces, nullptr);
+                                                                T, (uint32_t*)d_pieces, c->d_wide, nullptr);
             if (status == RTS_OK && e == hipSuccess) e = hipDeviceSynchronize();
         }
         if (d_cuts) (void)hipFree(d_cuts);
@@ -882,12 +839,133 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         t.blocksX = blocksX; t.blocksY = keyBlocksY;
         t.d_skipMap = (uint32_t*)d_map; t.d_pieces = (uint32_t*)d_pieces;
         t.nPieces = nPieces; t.pieceRows = (nPieces + blocksX - 1) / blocksX; t.nTiles = T;
+        t.plan = *plan; t.plan.prev_stats = nullptr; t.plan.prev_realtime = nullptr; t.plan.prev_waves = 0;
         if (tiles_out) *tiles_out = T;
         if (pieces_out) *pieces_out = nPieces;
     } catch (...) {
         c->planning = nullptr;
         return RTS_ERR_CAPACITY;                       // no exception crosses the C ABI
     }
+    return RTS_OK;
+}
+
+// Picks the kernel for THIS dispatch by timing the candidates on it (what a renderer does once per scene and resolution):
+// the lane-per-ray walk with work sharing, the packet kernel, the wide packet kernel (when the stream has a private copy).
+// Then, for a packet kernel, two launch parameters that are worth 2-6 % on some frames and cost as much on others
+// (profiles/r03/autotune_stage2_sweep.log): the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile
+// rows are started ("row_order" top-down or bottom-up: the rows started last are the kernel's tail).  Third stage (round 4):
+// a split table for the tiles measured to be long (rts_ctx_plan_splits), kept when it gains 1.5 % -- frames whose time is a
+// few long waves (atrium 1080p: -30 %), and the stripes of a multi-GPU frame; a frame that is throughput-bound to its end
+// (city, courtyard at 4K) keeps the plain launch.  Leaves the options and the table of the winners installed.  Results
+// never depend on any of them.
+static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                        uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                        int* chosen, float* ms_out) {
+    if (!c || !k || !d_positions || !d_mask) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    clearSplits(c);
+    int status = RTS_OK;
+    auto median5 = [&](float* out) {          // two untimed launches, then the median of five
+        float times[5];
+        for (int i = -2; i < 5; ++i) {
+            hipError_t e = hipEventRecord(c->ev0, nullptr);
+            if (e != hipSuccess) { status = hipStatus(e); return false; }
+            status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+            if (status != RTS_OK) return false;
+            float ms = 0;
+            e = hipEventRecord(c->ev1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            if (e != hipSuccess) { status = hipStatus(e); return false; }
+            if (i >= 0) times[i] = ms;
+        }
+        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
+        *out = times[2];
+        return true;
+    };
+    // (the wide kernel first, and a later candidate must beat the best by 2 %: at equal frame time the wide kernel's waves
+    //  are shorter, which is what a striped multi-GPU frame needs -- tools/stripe_scaling.py)
+    const int candidates[3] = { rts::V_WIDE, rts::V_PACKET, rts::V_SHARE };
+    const int before = c->variant, shareBefore = c->packetShare, orderBefore = c->rowOrder;
+    auto giveUp = [&]() { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; clearSplits(c); return status; };
+    uint64_t pixels = (uint64_t)W * (row_end - row_begin);
+    if (n_stripes > 1) pixels /= n_stripes;
+    int best = before;
+    float bestMs = 1e30f;
+    for (int v : candidates) {
+        if (v == rts::V_WIDE && !c->wideCount) continue;
+        if (v == rts::V_SHARE && pixels > (1u << 20)) continue;                  // (never close on a big frame: skip its long launches)
+        c->variant = v;
+        float ms;
+        if (!median5(&ms)) return giveUp();
+        if (ms < bestMs * 0.98f) { bestMs = ms; best = v; }
+    }
+    c->variant = best;
+    if (best == rts::V_WIDE || best == rts::V_PACKET) {
+        // second stage, one parameter at a time; a change must gain 1.5 % to be kept (launch-to-launch noise is below 1 %)
+        float ms;
+        if (c->packetShare == 4) {
+            c->packetShare = 6;
+            if (!median5(&ms)) return giveUp();
+            if (ms < bestMs * 0.985f) bestMs = ms; else c->packetShare = shareBefore;
+        }
+        if (c->rowOrder == 0 && !c->d_tileOrder && !c->swizzle && n_stripes <= 1) {
+            c->rowOrder = 1;
+            if (!median5(&ms)) return giveUp();
+            if (ms < bestMs * 0.985f) bestMs = ms; else c->rowOrder = orderBefore;
+        }
+        // third stage: split tables.  Tiles that lived longer than a share of the dispatch and ended in its later part.
+        if (c->wideCount && c->blockWaves == 1 && !c->wideLane && (!light || light->nsamples <= 1) && c->useSplits) {
+            const float T = bestMs * 1000.f;                                      // us
+            const float trial[2][2] = { { 0.5f, 0.15f }, { 0.75f, 0.10f } };      // {ended after this share of T, lived longer than this share}
+            int kept = -1, installed = -1;
+            rts_split_plan plan{};
+            auto fill = [&](int i) {
+                plan = rts_split_plan{};
+                plan.end_after_us = trial[i][0] * T;
+                plan.min_life_us = trial[i][1] * T < 8.f ? 8.f : trial[i][1] * T;
+                plan.piece_us = plan.min_life_us * 0.5f;
+                plan.max_pieces = 8;
+            };
+            for (int i = 0; i < 2; ++i) {
+                fill(i);
+                uint32_t tiles = 0;
+                status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, &tiles, nullptr);
+                if (status != RTS_OK) return giveUp();
+                installed = i;
+                if (!tiles) continue;
+                if (!median5(&ms)) return giveUp();
+                if (ms < bestMs * 0.985f) { bestMs = ms; kept = i; }
+            }
+            if (kept < 0) clearSplits(c);
+            else if (kept != installed) {
+                fill(kept);
+                status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, nullptr, nullptr);
+                if (status != RTS_OK) return giveUp();
+            }
+        }
+    }
+    if (chosen) *chosen = best;
+    if (ms_out) *ms_out = bestMs;
+    return RTS_OK;
+}
+
+int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W,
+                     uint32_t H, uint8_t* d_mask, int* chosen, float* ms_out) {
+    if (W == 0 || H == 0) return RTS_ERR_INVALID_ARG;
+    return autotuneImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, chosen, ms_out);
+}
+
+int rts_ctx_autotune_stripes(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                             uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, int* chosen, float* ms_out) {
+    if (W == 0 || H == 0 || band_rows == 0 || band_rows % 8 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
+    if (n_stripes == 1) return autotuneImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, chosen, ms_out);
+    return autotuneImpl(c, k, light, d_positions, W, H, 0, H, band_rows, n_stripes, stripe, d_mask, chosen, ms_out);
+}
+
+int rts_ctx_get_split_plan(rts_ctx* c, rts_split_plan* out) {
+    if (!c || !out || !c->splits.valid) return RTS_ERR_INVALID_ARG;
+    *out = c->splits.plan;
     return RTS_OK;
 }
 
@@ -903,6 +981,16 @@ int rts_ctx_plan_splits_stripes(rts_ctx* c, const rts_constants* k, const rts_li
     if (W == 0 || H == 0 || band_rows == 0 || band_rows % 8 != 0 || n_stripes == 0 || stripe >= n_stripes) return RTS_ERR_INVALID_ARG;
     if (n_stripes == 1) return planSplitsImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, plan, tiles, pieces);
     return planSplitsImpl(c, k, light, d_positions, W, H, 0, H, band_rows, n_stripes, stripe, d_mask, plan, tiles, pieces);
+}
+
+// diagnostics: per piece of the installed table {tile x | y << 16, first node, end node, pieces of its tile} and the 100 MHz
+// stamps of its start and end in the last launch that used the table (option "piece_stats")
+int rts_ctx_read_piece_stats(rts_ctx* c, uint32_t* records, uint64_t* clocks, size_t pieces) {
+    if (!c || !c->splits.valid || pieces > c->splits.nPieces || (clocks && (!c->d_pieceClock || pieces > c->pieceClockCount))) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    if (records) RTS_HIP(hipMemcpy(records, c->splits.d_pieces, pieces * 32, hipMemcpyDeviceToHost));
+    if (clocks) RTS_HIP(hipMemcpy(clocks, c->d_pieceClock, pieces * 64, hipMemcpyDeviceToHost));
+    return RTS_OK;
 }
 
 int rts_ctx_clear_splits(rts_ctx* c) {

@@ -23,19 +23,24 @@ enum Variant {
 
 // Kernel argument block (passed by value; lives in the kernarg segment, read with scalar loads).
 struct TraceParams {
+    // ---- what a tile wave needs before it can ask for its G-buffer texel: 64 bytes, one batch of scalar loads -------------
+    const float4* positions;  // W x H RGBA32F, camera-relative (device)
+    uint8_t* mask;            // W x H bytes (device)
+    uint32_t W, H, rowBegin, rowEnd;
+    uint32_t pieceRows;       // rows of the 2-D grid that hold the pieces of split tiles (they come first); 0 without a table
+    uint32_t blocksX, blocksY;
+    uint32_t rowOrder;        // dispatch order of the tile rows (speed only): 0 first to last, 1 last to first, 2 middle row outwards
+    const uint32_t* skipMap;  // split tiles: bit (by * blocksX + bx) set: the tile's own wave has nothing to do (NULL: no split table)
+    uint32_t bandShift;       // interleaved stripes: log2(bandRows / 8) when that is a power of two, else 0xFFFFFFFF
+    uint32_t stripe;
+    // ------------------------------------------------------------------------------------------------------------------
+    uint32_t bandRows, nStripes;           // interleaved stripes (nStripes <= 1: plain rowBegin..rowEnd)
     const void* bvh;          // packed vec4 stream, SURVEY.md Appendix A (device)
     uint32_t bvhBytes;
     uint32_t bvhFinite;       // every float of the stream is finite -> FAST slab test is legal
     uint32_t bvhOrdered;      // ... and every inner node has bboxMin <= bboxMax -> ordered slab test is legal
-    // mask dispatch
-    const float4* positions;  // W x H RGBA32F, camera-relative (device)
-    uint8_t* mask;            // W x H bytes (device)
-    uint32_t W, H, rowBegin, rowEnd;
-    uint32_t bandRows, nStripes, stripe;   // interleaved stripes (nStripes <= 1: plain rowBegin..rowEnd)
-    uint32_t bandShift;                    // log2(bandRows / 8) when that is a power of two, else 0xFFFFFFFF
-    uint32_t blocksX, blocksY, nBlocks, gridBlocks, swizzle;
+    uint32_t nBlocks, gridBlocks, swizzle;
     uint32_t grid2d;            // 1: launched as a blocksX x blocksY grid in natural order (no swizzle, no order table)
-    uint32_t rowOrder;          // dispatch order of the tile rows (speed only): 0 first to last, 1 last to first, 2 middle row outwards
     float cam[3];
     uint32_t lightType, nsamples;
     uint32_t softSplit;         // soft shadows: 4 waves per tile, samples dealt over them (option "soft_split")
@@ -62,11 +67,12 @@ struct TraceParams {
     uint32_t wideLane;        // dissolved wide packets continue lane per ray over the WIDE nodes (0: over the stream, stackless)
     // split tiles (rts_ctx_plan_splits): tiles measured to be long are walked by several one-wave workgroups ("pieces"), each
     // over one index range of the node stream; the pieces occupy the first pieceRows rows of the 2-D grid (dispatched first)
-    const uint32_t* skipMap;  // bit (by * blocksX + bx) set: the tile's own wave ends in its prologue (NULL: no split table)
-    const uint32_t* pieces;   // 4 dwords per piece: {bx | by << 16, first node, end node, state slot | pieces of the tile << 24}
+    const uint32_t* pieces;   // 8 dwords per piece: {bx | by << 16, first node, end node, state slot | pieces of the tile << 24,
+                              //  byte offset of the wide node the piece starts at, 0, 0, 0}
     uint64_t* tileState;      // 2 u64 per split tile {lanes found occluded by any piece, pieces done}; zero between launches
     uint32_t* pieceLog;       // split planning only: per piece 1 + pieceLogCap dwords {count, node indices visited ...}
-    uint32_t nPieces, pieceRows, pieceLogCap;
+    uint64_t* pieceClock;     // diagnostics ("piece_stats"): per piece {100 MHz clock at its start, at its end}, or NULL
+    uint32_t nPieces, pieceLogCap;
     float offsets[64][4];
 };
 
@@ -82,6 +88,6 @@ hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream
 // planning: from the visit logs of `tiles` one-piece walks (p.pieceLog layout) to the piece table: tile t gets cuts[t].pieces
 // records starting at record firstPiece[t], its index ranges cut at the quantiles of its log
 hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const SplitCut* d_cuts, const uint32_t* d_firstPiece,
-                                uint32_t tiles, uint32_t* d_pieces, hipStream_t stream);
+                                uint32_t tiles, uint32_t* d_pieces, const void* d_wide, hipStream_t stream);
 
 } // namespace rts

@@ -199,10 +199,21 @@ struct PieceShare {
     uint64_t seen = 0;              // state[0] as of the previous request
     uint32_t* log = nullptr;        // split planning only: visit log of this piece {count, node indices ...}
     uint32_t logCap = 0, logCount = 0;
+    bool diag = false;              // "piece_stats": where a piece's time goes
+    uint64_t tPacketEnd = 0, tLaneStart = 0;
+    uint32_t nodes = 0, entries = 0;
+    // An agent-scope round trip takes 1-2 us (profiles/r04/piece_stats_*.log), several steps of a walk: the answer to the
+    // PREVIOUS request is looked at, then the next request is issued into the same registers (the asm ties the address to
+    // the look, so that the compiler neither hoists the load above it nor copies -- and therefore waits for -- its result).
     __device__ __forceinline__ uint64_t poll() {
-        const uint64_t got = seen;
-        seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seen >> 32));
+        // (a GLOBAL load: a flat one would also count as an LDS / scalar-memory operation and hold up the node fetches)
+        typedef __attribute__((address_space(1))) uint64_t* GlobalU64;
+        uint64_t addr = (uint64_t)(uintptr_t)state;
+        asm volatile("" : "+s"(addr) : "s"(lo), "s"(hi));
+        seen = __hip_atomic_load((GlobalU64)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((uint64_t)hi << 32) | lo;
     }
     __device__ __forceinline__ void publish(uint64_t lanes) {
         if (laneId() == 0) (void)__hip_atomic_fetch_or(state, lanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -240,7 +251,8 @@ __device__ __forceinline__ bool traverseShare(const NodeStream& bvh, Ray r, bool
     u32x4 a = bvh.vec4(active ? node * 2u : OOB_VEC4), b = bvh.vec4(active ? node * 2u + 1u : OOB_VEC4);
     for (;;) {
         if constexpr (TEAM) {
-            if ((iter & 3u) == 0) {
+            // (node fetches and this request return in order: every sixteenth iteration may wait for a round trip)
+            if ((iter & 15u) == 0) {
                 occludedOwners |= team->poll();
                 active = active && !((occludedOwners >> owner) & 1ull);
             }
@@ -970,12 +982,12 @@ __device__ __forceinline__ bool traverseWide(const TraceParams& p, const NodeStr
 // tile's 64 bytes and leaves the two words zero for the next launch.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const NodeStream& bvh, const Ray& r, const WideRay& w, uint64_t liveMask,
-                                                  uint32_t a, uint32_t b, PieceShare& team, uint32_t* lds) {
+                                                  uint32_t a, uint32_t b, uint32_t entryRef, PieceShare& team, uint32_t* lds) {
     const uint64_t wideAddr = uniform64(p.wide), triAddr = uniform64(p.tris);
     uint32_t stRef = 0, stLo = 0, stHi = 0;            // the stack: entry i lives in lane i (as in wideWalk)
     uint32_t sp = 0;
     uint64_t occ = 0;
-    uint32_t curRef = 0;
+    uint32_t curRef = entryRef;                        // the lowest wide node whose subtree holds [a, b): the levels above it only cull
     uint64_t curM = liveMask;
     bool have = true, dissolve = false;
     const uint32_t window = p.packetBudget, thr = p.packetBudget * p.packetShare;
@@ -990,6 +1002,32 @@ __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const No
     auto entryMask = [&](uint32_t e) {
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)stHi, (int)e) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)stLo, (int)e);
     };
+    if (!team.log) {
+        // The everyday piece: the loop in assembly (rts_wide_asm.inc: wideDescendRange), four pops at a time; in between, a
+        // look at what the other pieces found (the request of the previous look), and every fourth time the dissolve rule.
+        push(entryRef, liveMask);
+        const float tmaxUniform = p.lightType == 0 ? 1e9f : 1.0f;
+        const void* const wb = (const void*)(uintptr_t)wideAddr;
+        const void* const tb = (const void*)(uintptr_t)triAddr;
+        const uint32_t thr16 = 16u * p.packetShare;
+        uint32_t turns = 0;
+        uint64_t told = 0;                                              // what this piece has published
+        for (;;) {
+            const uint32_t st = wideDescendRange(wb, tb, r, w, tmaxUniform, a, b, occ, sp, stRef, stLo, stHi, acc, 4u);
+            if (team.diag) team.nodes += 4u;
+            if (occ & ~told) { team.publish(occ & ~told); told = occ; }
+            if (st == 0) break;
+            if (st == 1) { dissolve = true; break; }
+            occ |= team.poll();
+            told |= occ;
+            if ((liveMask & ~occ) == 0) { sp = 0; break; }
+            if (++turns == 4u) {
+                const uint32_t alive = (uint32_t)__builtin_popcountll(liveMask & ~occ);
+                if (acc * 16u < alive * thr16) { dissolve = true; break; }
+                acc = 0; turns = 0;
+            }
+        }
+    } else
     for (;;) {
         if (!have) {
             if (sp == 0) break;
@@ -999,8 +1037,8 @@ __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const No
             if (curM == 0) continue;
         }
         have = false;
-        if (--pollLeft == 0) {                                          // rays another piece found occluded (as of four nodes ago)
-            pollLeft = 4;
+        if (--pollLeft == 0) {                                          // rays another piece found occluded (as of eight nodes ago)
+            pollLeft = 8;
             occ |= team.poll();
             if ((liveMask & ~occ) == 0) { sp = 0; break; }
             curM &= ~occ;
@@ -1023,6 +1061,7 @@ __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const No
         const uint32_t ref[4] = { n1[8], n1[9], n1[10], n1[11] };
         const uint32_t self = n1[12];
         const uint32_t idx[4] = { self + 1u, n1[13], n1[14], n1[15] };   // first node of slot k's subtree (slot 0: a lower bound)
+        if (team.diag) ++team.nodes;
         if (team.log) {                                                   // planning: a packet node weighs eight lane visits
             const uint32_t at = team.logCount + laneId();
             if (laneId() < 8u && at < team.logCap) team.log[1u + at] = self;
@@ -1064,6 +1103,7 @@ __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const No
         }
         if (candM != 0) { curRef = candRef; curM = candM; have = true; }
     }
+    if (team.diag) { team.tPacketEnd = __builtin_amdgcn_s_memrealtime(); team.entries = sp; }
     if (!dissolve) return occ;
     // lane per ray from here: every ray from the lowest node it is pending on, but not before a, and not beyond b
     uint32_t start = END;
@@ -1075,15 +1115,16 @@ __device__ __forceinline__ uint64_t wideWalkRange(const TraceParams& p, const No
         if (__builtin_amdgcn_inverse_ballot_w64(m)) start = self < start ? self : start;
     }
     if (start != END && start < a) start = a;
+    if (team.diag) team.tLaneStart = __builtin_amdgcn_s_memrealtime();
     const bool h = traverseShare<true, true, true>(bvh, r, start != END, start, lds, nullptr, p.parents, b, &team);
     return occ | __builtin_amdgcn_ballot_w64(h);
 }
 
 // One piece: the lanes (rays of the tile) it found occluded inside [a, b).
 __device__ __forceinline__ uint64_t traversePiece(const TraceParams& p, const NodeStream& bvh, const Ray& r, bool live, uint32_t a, uint32_t b,
-                                                  PieceShare& team, uint32_t* lds) {
+                                                  uint32_t entryRef, PieceShare& team, uint32_t* lds) {
     const uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);
-    if (liveMask == 0) return 0;
+    if (liveMask == 0 || a >= b) return 0;                               // (an empty range: more pieces than the log had cuts for)
     const u32x8 root = *(ConstNodePtr)(uintptr_t)uniform64(p.bvh);
     const float rootLo[3] = { __uint_as_float(root.s0), __uint_as_float(root.s1), __uint_as_float(root.s2) };
     const float rootHi[3] = { __uint_as_float(root.s4), __uint_as_float(root.s5), __uint_as_float(root.s6) };
@@ -1093,7 +1134,7 @@ __device__ __forceinline__ uint64_t traversePiece(const TraceParams& p, const No
         if (a != 0u) return 0;
         return __builtin_amdgcn_ballot_w64(traverseShare<false>(bvh, r, live, 0u, lds));
     }
-    return wideWalkRange(p, bvh, r, w, liveMask, a, b, team, lds);
+    return wideWalkRange(p, bvh, r, w, liveMask, a, b, entryRef, team, lds);
 }
 
 template <int VARIANT, bool FAST>
@@ -1201,6 +1242,71 @@ __global__ __launch_bounds__(256) void shadowMaskKernel(TraceParams p) {
     if (live) __builtin_nontemporal_store((uint8_t)lit, &p.mask[pix]);   // comp:150
 }
 
+// One piece of a split tile, start to end (called by the first pieceRows rows of a TILESPLIT launch): the tile's rays are
+// set up as by its own wave (comp:128-146), walked over the piece's index range, and the piece that finishes last stores
+// the tile.
+template <bool BANDS>
+__device__ __forceinline__ void runPiece(const TraceParams& p, uint32_t* lds) {
+    const uint32_t pieceId = blockIdx.y * gridDim.x + blockIdx.x;
+    if (pieceId >= p.nPieces) return;
+    const u32x8 rec8 = *(ConstNodePtr)(uintptr_t)(uniform64(p.pieces) + (uint64_t)pieceId * 32u);
+    const u32x4 rec{ rec8.s0, rec8.s1, rec8.s2, rec8.s3 };
+    const uint32_t bx = rec.x & 0xFFFFu, by = rec.x >> 16, pieceCount = rec.w >> 24;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t x = bx * 8u + (lane & 7u);
+    uint32_t y;
+    if constexpr (BANDS) {
+        const uint32_t band = by >> p.bandShift, within = by - (band << p.bandShift);
+        y = (band * p.nStripes + p.stripe) * p.bandRows + within * 8u + (lane >> 3);
+    } else y = p.rowBegin + by * 8u + (lane >> 3);
+    const bool live = (x < p.W) && (y < p.rowEnd);
+    const size_t pix = (size_t)y * p.W + x;
+    F3 rel{ 0.f, 0.f, 0.f };
+    if (live) {
+        f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix);          // comp:135
+        rel = F3{ t.x, t.y, t.z };
+    }
+    const uint64_t tBegin = p.pieceClock ? __builtin_amdgcn_s_memrealtime() : 0;
+    PieceShare team;
+    team.diag = p.pieceClock != nullptr;
+    team.state = p.tileState + (size_t)(rec.w & 0xFFFFFFu) * 2u;
+    if (p.pieceLog) { team.log = p.pieceLog + (size_t)pieceId * (p.pieceLogCap + 1u); team.logCap = p.pieceLogCap; }
+    const NodeStream bvh = openStream(p);
+    const Ray r = makeShadowRay(p, rel, 0u, (uint32_t)pix);
+    uint64_t tReady = 0;
+    if (p.pieceClock) { asm volatile("" :: "v"(r.inv.x), "v"(r.inv.y), "v"(r.inv.z), "v"(r.o.x)); tReady = __builtin_amdgcn_s_memrealtime(); }
+    const uint64_t occ = traversePiece(p, bvh, r, live, rec.y, rec.z, rec8.s4, team, lds);
+    if (team.log && lane == 0) team.log[0] = team.logCount < team.logCap ? team.logCount : team.logCap;
+    const uint64_t tWalked = p.pieceClock ? __builtin_amdgcn_s_memrealtime() : 0;
+    // The piece that finishes last stores the tile.  Both atomics return a value, and the count is only added once the OR
+    // has been performed (its result is an operand of the add as far as the compiler can tell), so the piece that reads
+    // pieceCount - 1 finds every other piece's lanes in state[0].
+    uint32_t done = 0;
+    if (lane == 0) {
+        const uint64_t before = __hip_atomic_fetch_or(team.state, occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t one = 1;
+        asm volatile("; the count follows the OR" : "+v"(one) : "v"(before));
+        done = (uint32_t)__hip_atomic_fetch_add(team.state + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
+    if (p.pieceClock && lane == 0) {                                  // diagnostics: 8 u64 per piece
+        uint64_t* o = p.pieceClock + (size_t)pieceId * 8u;
+        o[0] = tBegin; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tReady; o[3] = team.tPacketEnd; o[4] = team.tLaneStart; o[5] = tWalked;
+        o[6] = (uint64_t)team.nodes | ((uint64_t)team.entries << 32); o[7] = occ;
+    }
+    if (done + 1u != pieceCount) return;
+    uint64_t all = 0;
+    if (lane == 0) {
+        all = __hip_atomic_fetch_or(team.state, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t zero = 0;
+        asm volatile("; the reset follows the read" : "+v"(zero) : "v"(all));
+        __hip_atomic_store(team.state, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(team.state + 1, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    all = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(all >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)all);
+    if (live) __builtin_nontemporal_store((uint8_t)(((all >> lane) & 1ull) ? 0u : 1u), &p.mask[pix]);   // comp:148-150
+}
+
 // Packet kernels: a wave is a (8 or 16) x (8 or 16) pixel tile, a lane carries K = 1, 2 or 4 rays (the
 // 8x8 sub-tiles of its wave tile), a 256-thread block is 2x2 wave tiles.
 // WPB = waves per block: 4 (block = 2x2 wave tiles) or 1 (block = one wave tile, so that a finished wave
@@ -1239,22 +1345,26 @@ void shadowMaskPacketKernel(TraceParams p) {
     __shared__ uint32_t partial[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 64 : 1];                          // per-wave counts of unoccluded samples
     constexpr uint32_t TW = K >= 2 ? 16u : 8u, TH = K >= 4 ? 16u : 8u;
     uint32_t bx = blockIdx.x, by = 0;
-    bool piece = false;
-    uint32_t pieceA = 0, pieceB = END, pieceSlot = 0, pieceCount = 1, pieceId = 0;
+    bool mine = true;
+    if constexpr (PLAIN) {
+        // Everything a tile wave needs before it can ask for its texel is the first 64 bytes of the argument block: asked for
+        // here in one batch (the compiler would fetch each field where it is first used: three or four dependent round
+        // trips to the scalar cache in front of the texel request).
+        const uint64_t posAddr = (uint64_t)(uintptr_t)p.positions, mapAddr = (uint64_t)(uintptr_t)p.skipMap;
+        const uint32_t a0 = p.W, a1 = p.rowBegin, a2 = p.rowEnd, a3 = p.pieceRows, a4 = p.blocksX, a5 = p.blocksY, a6 = p.rowOrder,
+                       a7 = p.bandShift, a8 = p.stripe;
+        asm volatile("" :: "s"(posAddr), "s"(mapAddr), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8));
+    }
     if constexpr (TILESPLIT) {
-        if (blockIdx.y < p.pieceRows) {                               // a piece of a split tile
-            pieceId = blockIdx.y * gridDim.x + blockIdx.x;
-            if (pieceId >= p.nPieces) return;
-            const u32x4 rec = *(ConstVec4Ptr)(uintptr_t)(uniform64(p.pieces) + (uint64_t)pieceId * 16u);
-            bx = rec.x & 0xFFFFu; by = rec.x >> 16;
-            pieceA = rec.y; pieceB = rec.z; pieceSlot = rec.w & 0xFFFFFFu; pieceCount = rec.w >> 24;
-            piece = true;
-        } else {
-            by = dispatchRow(p, blockIdx.y - p.pieceRows);
-            const uint32_t tile = by * p.blocksX + bx;
-            const uint32_t word = *(ConstU32Ptr)(uintptr_t)(uniform64(p.skipMap) + (uint64_t)(tile >> 5) * 4u);
-            if ((word >> (tile & 31u)) & 1u) return;                   // walked by its pieces
-        }
+        const uint32_t pieceRows = p.pieceRows, blocksX = p.blocksX, blocksY = p.blocksY, rowOrder = p.rowOrder;
+        const uint64_t mapAddr = uniform64(p.skipMap);
+        if (blockIdx.y < pieceRows) { runPiece<BANDS>(p, lds); return; }        // a piece of a split tile: a path of its own
+        const uint32_t k = blockIdx.y - pieceRows;
+        by = rowOrder == 1u ? blocksY - 1u - k : (rowOrder == 2u ? ((k & 1u) ? (blocksY >> 1) - ((k + 1u) >> 1) : (blocksY >> 1) + (k >> 1)) : k);
+        // the tile's bit of the split table (the word travels with the next batch of kernel arguments)
+        const uint32_t bit = by * blocksX + bx;
+        const uint32_t word = *(ConstU32Ptr)(uintptr_t)(mapAddr + (uint64_t)(bit >> 5) * 4u);
+        mine = !((word >> (bit & 31u)) & 1u);                        // a split tile is walked by its pieces: nobody is live here
     } else by = dispatchRow(p, blockIdx.y);                           // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1271,58 +1381,32 @@ void shadowMaskPacketKernel(TraceParams p) {
             const uint32_t band = by >> p.bandShift, within = by - (band << p.bandShift);
             y = (band * p.nStripes + p.stripe) * p.bandRows + within * 8u + (lane >> 3);
         } else y = PLAIN ? p.rowBegin + v0 + (k >> 1) * 8u : ownedRow(p, v0 + (k >> 1) * 8u);
-        live[k] = (x < p.W) && (y < p.rowEnd);
+        live[k] = (x < p.W) && (y < p.rowEnd) && mine;
         pix[k] = (size_t)y * p.W + x;
-        rel[k] = F3{ 0.f, 0.f, 0.f };
-        if (live[k]) {
-            f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix[k]);   // comp:135
+        if constexpr (PLAIN) {
+            // (no branch around the request: a lane without a pixel asks for texel 0 and never looks at it -- with the branch
+            //  the compiler waits for the texel inside it, before the rest of the prologue's scalar work)
+            const f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + (live[k] ? pix[k] : (size_t)0));   // comp:135
             rel[k] = F3{ t.x, t.y, t.z };
+        } else {
+            rel[k] = F3{ 0.f, 0.f, 0.f };
+            if (live[k]) {
+                f32x4 t = __builtin_nontemporal_load((const f32x4*)p.positions + pix[k]);   // comp:135
+                rel[k] = F3{ t.x, t.y, t.z };
+            }
         }
     }
     const NodeStream bvh = openStream(p);
     const uint32_t ns = SOFT ? p.nsamples : 1u;
     // clock probe (every instantiation, so that the clock is measured on the launches that are timed): one wave per tile row
     // (the stamps go straight to memory: nothing of the probe stays in registers across the walk)
-    const uint32_t probeRow = TILESPLIT ? blockIdx.y - p.pieceRows : (p.grid2d ? blockIdx.y : 0u);
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && !piece) {
+    const uint32_t probeRow = TILESPLIT ? blockIdx.y - p.pieceRows : (p.grid2d ? blockIdx.y : 0u);   // (read under p.clockProbe only)
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
     }
     const uint64_t tStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memtime() : 0;   // diagnostics only
     const uint64_t rStart = !PLAIN && p.waveStats ? __builtin_amdgcn_s_memrealtime() : 0;
-    if constexpr (TILESPLIT) {
-        if (piece) {
-            PieceShare team;
-            team.state = p.tileState + (size_t)pieceSlot * 2u;
-            if (p.pieceLog) { team.log = p.pieceLog + (size_t)pieceId * (p.pieceLogCap + 1u); team.logCap = p.pieceLogCap; }
-            const Ray r = makeShadowRay(p, rel[0], 0u, (uint32_t)pix[0]);
-            const uint64_t occ = traversePiece(p, bvh, r, live[0], pieceA, pieceB, team, lds);
-            if (team.log && lane == 0) team.log[0] = team.logCount < team.logCap ? team.logCount : team.logCap;
-            // The piece that finishes last stores the tile.  Both atomics return a value, and the count is only added once
-            // the OR has been performed (its result is an operand of the add as far as the compiler can tell), so the piece
-            // that reads pieceCount - 1 finds every other piece's lanes in state[0].
-            uint32_t done = 0;
-            if (lane == 0) {
-                const uint64_t before = __hip_atomic_fetch_or(team.state, occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint64_t one = 1;
-                asm volatile("; the count follows the OR" : "+v"(one) : "v"(before));
-                done = (uint32_t)__hip_atomic_fetch_add(team.state + 1, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
-            if (done + 1u != pieceCount) return;
-            uint64_t all = 0;
-            if (lane == 0) {
-                all = __hip_atomic_fetch_or(team.state, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint64_t zero = 0;
-                asm volatile("; the reset follows the read" : "+v"(zero) : "v"(all));
-                __hip_atomic_store(team.state, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(team.state + 1, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            all = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(all >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)all);
-            if (live[0]) __builtin_nontemporal_store((uint8_t)(((all >> lane) & 1ull) ? 0u : 1u), &p.mask[pix[0]]);   // comp:148-150
-            return;
-        }
-    }
     int32_t left = 0;
     ShareDiag shareDiag;
     shareDiag.on = !PLAIN && p.waveStats != nullptr;
@@ -1360,7 +1444,7 @@ void shadowMaskPacketKernel(TraceParams p) {
         for (int k = 0; k < K; ++k)
             if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
     }
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && !piece) {
+    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -1523,8 +1607,30 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
 // the bin that holds the quantile until a bin is one index wide).  Piece j of the tile is [cut_j, cut_j+1), cut_0 = 0,
 // cut_S = END; a tile whose log is empty gets one piece that covers everything and S - 1 empty ones.
 // ------------------------------------------------------------------------------------------------
+// The wide node a piece starts at: the lowest one whose subtree holds all of [a, b) -- found by walking down from the root
+// while one inner slot's index range [lo_k, idx_k+1) holds the piece's (the levels skipped only cull: the piece's hits are
+// confirmed against the leaf's parent box like every hit of the wide kernels).
+__device__ uint32_t pieceEntry(const uint32_t* wide, uint32_t a, uint32_t b) {
+    uint32_t ref = 0, end = END;
+    for (int depth = 0; depth < 512; ++depth) {
+        const uint32_t* n = wide + (ref >> 2);
+        const uint32_t self = n[28];
+        uint32_t next = END, nextEnd = END;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rk = n[24 + k];
+            if (rk == END || (rk & 1u)) continue;
+            const uint32_t lo = k ? n[28 + k] : self + 1u;
+            const uint32_t hi = (k < 3 && n[24 + k + 1] != END) ? n[28 + k + 1] : end;
+            if (lo <= a && b <= hi) { next = rk; nextEnd = hi; }
+        }
+        if (next == END) break;
+        ref = next; end = nextEnd;
+    }
+    return ref;
+}
+
 __global__ __launch_bounds__(256) void splitQuantilesKernel(const uint32_t* log, uint32_t cap, const SplitCut* cuts, const uint32_t* firstPiece,
-                                                            uint32_t tiles, uint32_t* pieces) {
+                                                            uint32_t tiles, uint32_t* pieces, const uint32_t* wide) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t box[4];                       // [0] min, [1] max, then the refinement's {lo, hi}
     __shared__ uint32_t below;
@@ -1572,17 +1678,19 @@ __global__ __launch_bounds__(256) void splitQuantilesKernel(const uint32_t* log,
         }
         if (cut < prevCut) cut = prevCut;
         if (threadIdx.x == 0) {
-            uint32_t* o = pieces + (size_t)(base + j) * 4u;
+            uint32_t* o = pieces + (size_t)(base + j) * 8u;
             o[0] = cuts[t].tile; o[1] = prevCut; o[2] = cut; o[3] = t | (S << 24);
+            o[4] = prevCut < cut ? pieceEntry(wide, prevCut, cut) : 0u; o[5] = 0; o[6] = 0; o[7] = 0;
         }
         prevCut = cut;
     }
 }
 
 hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const SplitCut* d_cuts, const uint32_t* d_firstPiece,
-                                uint32_t tiles, uint32_t* d_pieces, hipStream_t stream) {
+                                uint32_t tiles, uint32_t* d_pieces, const void* d_wide, hipStream_t stream) {
     if (tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(splitQuantilesKernel, dim3(tiles), dim3(256), 0, stream, d_log, logCap, d_cuts, d_firstPiece, tiles, d_pieces);
+    hipLaunchKernelGGL(splitQuantilesKernel, dim3(tiles), dim3(256), 0, stream, d_log, logCap, d_cuts, d_firstPiece, tiles, d_pieces,
+                       (const uint32_t*)d_wide);
     return hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 """Experiment (GPU box): split tables (rts_ctx_plan_splits) against the plain launch, same process, same clocks.
 For every config and base kernel: the frame without a table, then with tables planned at several (min_life_us, piece_us,
 max_pieces); per point the median / minimum of N launches between HIP events, back-to-back wall time, and the number of mask
-bytes that differ from the oracle's.
-    KERNELS=3,8 PLANS=20:8:8,40:10:8 python tests/experiments/split_ab.py atrium_1080p courtyard_4k city_4k"""
+bytes that differ from the oracle's.  A plan is life:piece:max_pieces[:end fraction].
+    KERNELS=3,8 PLANS=20:8:8,40:10:8:0.7 python tests/experiments/split_ab.py atrium_1080p courtyard_4k city_4k"""
 import os
 import sys
 import time
@@ -62,13 +62,15 @@ for cfg in sys.argv[1:] or ["atrium_1080p"]:
             ctx.clear_splits()
             med, mn, b2b = timeit(ctx, go, N)
             print(f"{cfg} kernel {k} no table: median {med:.4f} ms, min {mn:.4f}, back to back {b2b:.4f}; {check()} bytes differ ({ctx.last_kernel_name()})", flush=True)
-            for life, piece, maxp in PLANS:
+            for life, piece, maxp, *rest in PLANS:
+                endfrac = rest[0] if rest else 0.0           # tiles that ended later than this fraction of the plain frame
                 t0 = time.perf_counter()
-                tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_m, light=wl.light, min_life_us=life, piece_us=piece, max_pieces=int(maxp))
+                tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_m, light=wl.light, min_life_us=life, piece_us=piece, max_pieces=int(maxp),
+                                                end_after_us=endfrac * med * 1e3)
                 plan_ms = (time.perf_counter() - t0) * 1e3
                 bad = check()
                 med2, mn2, b2b2 = timeit(ctx, go, N)
-                print(f"{cfg} kernel {k} table life>{life:g}us piece {piece:g}us max {int(maxp)}: {tiles} tiles, {pieces} pieces (planned in {plan_ms:.0f} ms): "
+                print(f"{cfg} kernel {k} table life>{life:g}us end>{endfrac:g}T piece {piece:g}us max {int(maxp)}: {tiles} tiles, {pieces} pieces (planned in {plan_ms:.0f} ms): "
                       f"median {med2:.4f} ms ({(med2 / med - 1) * 100:+.1f} %), min {mn2:.4f}, back to back {b2b2:.4f}; {bad} bytes differ", flush=True)
             ctx.clear_splits()
         ctx.free(d_pos); ctx.free(d_m)

@@ -499,6 +499,204 @@ def test_stream_with_orphan_nodes_gets_no_private_copy(ctx):
     ctx.set_option("kernel", -1)
 
 
+def _device_frame(ctx, wl, d_pos, d_mask, **kw):
+    got = np.full((wl.H, wl.W), 9, np.uint8)
+    ctx.h2d(d_mask, got)
+    ctx.trace_shadow_mask_device(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, **kw)
+    ctx.synchronize()
+    ctx.d2h(got, d_mask)
+    return got
+
+
+def test_split_tables_never_change_the_mask(ctx):
+    """rts_ctx_plan_splits: tiles measured to be long are walked by several one-wave pieces, each over one index range of the
+    stream.  Whatever the table -- few tiles or thousands, 2 or 16 pieces, planned from this frame, from another camera's
+    frame or from statistics handed in -- the mask is the oracle's; the table is only used by the dispatch it was planned for,
+    and dropped with the stream."""
+    wl = workloads.prepare("atrium", 960, 540)
+    W, H = wl.W, wl.H
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+    ctx.set_bvh(wl.packed)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        for kernel in (3, 8):
+            ctx.set_option("kernel", kernel)
+            for life, piece, maxp, end in ((40.0, 10.0, 8, 0.0), (10.0, 3.0, 16, 0.0), (3.0, 1.0, 4, 0.0), (15.0, 5.0, 8, 40.0)):
+                tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=life, piece_us=piece,
+                                                max_pieces=maxp, end_after_us=end)
+                assert ctx.get_option("split_tiles") == tiles and ctx.get_option("split_pieces") == pieces
+                assert pieces >= 2 * tiles
+                got = _device_frame(ctx, wl, d_pos, d_mask)
+                assert (got == want).all(), (kernel, life, piece, maxp, tiles, int((got != want).sum()))
+            assert tiles > 100                                            # the aggressive plans really split many tiles
+            plan = ctx.split_plan()
+            assert plan is not None and plan["max_pieces"] == 8 and abs(plan["min_life_us"] - 15.0) < 1e-6
+            # the table is for the full-frame dispatch only: a row range runs without it, and is right
+            got = np.full((H, W), 9, np.uint8)
+            ctx.h2d(d_mask, got)
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light, row_begin=64, row_end=200)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            assert (got[64:200] == want[64:200]).all() and (got[:64] == 9).all() and (got[200:] == 9).all()
+            # "tile_splits" 0 ignores the table
+            ctx.set_option("tile_splits", 0)
+            assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()
+            ctx.set_option("tile_splits", 1)
+            # another camera (the G-buffer of a frame 3 % further along the view direction) through the SAME table
+            sc = wl.scene
+            eye2 = (sc.eye + (sc.target - sc.eye) * np.float32(0.03)).astype(np.float32)
+            pos2, _ = api.primary_positions(wl.packed, eye2, sc.target, sc.fovy, W, H)
+            k2 = api.RayTracingConstants.make(eye2, [0.3, 0.8, 0.5], W, H)
+            want2, _, _ = oracle.shadow_mask(wl.packed, k2.as_array(), oracle.light_from_product(wl.light, k2), pos2, W, H)
+            d_pos2 = ctx.malloc(pos2.nbytes)
+            ctx.h2d(d_pos2, pos2)
+            got = np.full((H, W), 9, np.uint8)
+            ctx.h2d(d_mask, got)
+            ctx.trace_shadow_mask_device(k2, d_pos2, W, H, d_mask, light=wl.light)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            ctx.free(d_pos2)
+            assert ctx.get_option("split_tiles") > 0 and (got == want2).all(), (kernel, "moved camera", int((got != want2).sum()))
+            # statistics of an earlier frame handed in instead of a measuring launch
+            waves = ((W + 7) // 8) * ((H + 7) // 8)
+            ctx.clear_splits()
+            ctx.set_option("wave_stats", waves)
+            _device_frame(ctx, wl, d_pos, d_mask)
+            st, rt = ctx.read_wave_stats(waves), ctx.read_wave_realtime(waves)
+            ctx.set_option("wave_stats", 0)
+            tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=20.0, piece_us=5.0, max_pieces=8,
+                                            prev=(st, rt))
+            assert tiles > 0
+            assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()
+            # two frames in flight on two streams share the table, not its state
+            s0, s1 = ctx.stream_create(), ctx.stream_create()
+            d_mask2 = ctx.malloc(W * H)
+            for rep in range(3):
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light, stream=s0)
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask2, light=wl.light, stream=s1)
+            ctx.synchronize(s0); ctx.synchronize(s1)
+            for d in (d_mask, d_mask2):
+                got = np.zeros((H, W), np.uint8)
+                ctx.d2h(got, d)
+                assert (got == want).all()
+            ctx.free(d_mask2)
+            ctx.stream_destroy(s0); ctx.stream_destroy(s1)
+        # a new stream drops the table
+        ctx.set_bvh(wl.packed)
+        assert ctx.get_option("split_tiles") == 0 and ctx.split_plan() is None
+        # interleaved stripes: a table per stripe dispatch
+        ctx.set_option("kernel", 8)
+        got = np.full((H, W), 9, np.uint8)
+        ctx.h2d(d_mask, got)
+        for r in range(3):
+            tiles, _ = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=8.0, piece_us=3.0, max_pieces=8,
+                                       stripes=(32, 3, r))
+            assert tiles > 0
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 3, r, light=wl.light)
+        ctx.synchronize()
+        ctx.d2h(got, d_mask)
+        assert (got == want).all(), int((got != want).sum())
+    finally:
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1)
+        ctx.set_option("tile_splits", 1)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
+def test_split_tables_on_awkward_streams_and_rays(ctx):
+    """Pieces on the hand-made deep tree (their stack limit and the lane-per-ray continuation inside an index range), with an
+    axis-parallel light (every wave takes the exact walk: piece 0 walks it whole, the others contribute nothing), on a ragged
+    frame, and with soft shadows (no table is planned for them)."""
+    packed = _deep_bushy_stream(25)
+    W = H = 24
+    pos = np.zeros((H, W, 4), np.float32)
+    pos[..., 0] = 0.2 + 0.6 * (np.arange(W, dtype=np.float32)[None, :] + 0.5) / W
+    pos[..., 1] = 0.2 + 0.6 * (np.arange(H, dtype=np.float32)[:, None] + 0.5) / H
+    ctx.set_bvh(packed)
+    d_pos, d_mask = ctx.malloc(pos.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, pos)
+        for direction in ([0.001, 0.002, 1.0], [0.0, 0.0, 1.0]):
+            k = api.RayTracingConstants.make([0, 0, 0], direction, W, H)
+            want, _, _ = oracle.shadow_mask(packed, k.as_array(), oracle.light_from_product(None, k), pos, W, H)
+            for kernel in (3, 8):
+                for share in (4, 0):
+                    ctx.set_option("kernel", kernel)
+                    ctx.set_option("packet_share", share)
+                    tiles, pieces = ctx.plan_splits(k, d_pos, W, H, d_mask, min_life_us=0.5, piece_us=0.5, max_pieces=16)
+                    assert tiles == 9 and pieces > 18
+                    got = np.full((H, W), 9, np.uint8)
+                    ctx.h2d(d_mask, got)
+                    ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask)
+                    ctx.synchronize()
+                    ctx.d2h(got, d_mask)
+                    assert (got == want).all(), (direction, kernel, share, int((got != want).sum()))
+    finally:
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1)
+        ctx.set_option("packet_share", 4)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+    wl = workloads.prepare("cornell", 250, 131, via_obj=False)
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants), wl.positions, wl.W, wl.H)
+    ctx.set_bvh(wl.packed)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(wl.W * wl.H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        ctx.set_option("kernel", 3)
+        tiles, _ = ctx.plan_splits(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, min_life_us=2.0, piece_us=1.0, max_pieces=8)
+        assert tiles > 0
+        assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()
+        soft = workloads.relight(wl, "point", 16)
+        with pytest.raises(api.RtsError):
+            ctx.plan_splits(soft.constants, d_pos, wl.W, wl.H, d_mask, light=soft.light)
+    finally:
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
+@pytest.mark.parametrize("name", ["atrium_1080p", "city_4k", "courtyard_4k"])
+def test_split_tables_full_size(ctx, name):
+    """The BASELINE frames at their own size through split tables: the table rts_ctx_autotune keeps (if it keeps one), and a
+    forced one (every tile that lived longer than 25 us in 4..8 pieces) under both packet kernels and as 8 interleaved stripes."""
+    wl = workloads.prepare_config(name)
+    W, H = wl.W, wl.H
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+    ctx.set_bvh(wl.packed)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+        chosen, ms = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        assert chosen in (3, 8)
+        if name == "atrium_1080p":
+            assert ctx.get_option("split_tiles") > 0                        # its frame is a few long waves: the table must win
+        assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all(), "autotuned"
+        for kernel in (3, 8):
+            ctx.set_option("kernel", kernel)
+            tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=25.0, piece_us=6.0, max_pieces=8)
+            assert tiles > 0
+            got = _device_frame(ctx, wl, d_pos, d_mask)
+            assert (got == want).all(), (kernel, tiles, int((got != want).sum()))
+        got = np.full((H, W), 9, np.uint8)
+        ctx.h2d(d_mask, got)
+        for r in range(8):
+            ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light, stripes=(32, 8, r))
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 8, r, light=wl.light)
+        ctx.synchronize()
+        ctx.d2h(got, d_mask)
+        assert (got == want).all(), ("8 tuned stripes", int((got != want).sum()))
+    finally:
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+        ctx.free(d_pos)
+        ctx.free(d_mask)
+
+
 def test_non_finite_bvh_takes_the_exact_path(ctx):
     """A packed buffer from another producer may carry Inf boxes: the fast slab test must not be used."""
     sc = scenes.terrain(9)

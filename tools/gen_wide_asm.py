@@ -303,6 +303,139 @@ def loop(octant):
     return L
 
 
+def loop_range():
+    """The loop of a PIECE of a split tile (rts_kernels.hip, 'SPLIT TILES'): the generic form of loop() with
+      * a range filter: the node's dwords 28..31 {own index, first index of slots 1..3} travel in T0..T3 until the filter has
+        used them; slot k covers the index range [lo_k, idx_k+1) (lo_0 = own index + 1, a lower bound; an empty slot's index
+        is END) and is dropped when it starts at or after %[rb] or ends at or before %[ra];
+      * one entry: a POP (the caller pushes the node to start with; the loop pushes back the node it returns on);
+      * a return after %[budget] + 1 pops (status 2: the caller looks at what the other pieces found, applies the dissolve
+        rule to %[acc] = members picked up, and comes back), on a full stack (1) or when the stack is empty (0).  The status
+        leaves in %[budget]."""
+    octant = 8
+    L = [f"s_mov_b64 {R}, exec",
+         f"v_writelane_b32 %[vlo], {RLO}, 63",
+         f"v_writelane_b32 %[vhi], {RHI}, 63",
+         "s_branch 5f",
+         # ---- one node --------------------------------------------------------------------------------------------
+         "1:",
+         f"s_load_dwordx16 s[{BASE}:{BASE + 15}], %[wb], {REF}",
+         f"s_load_dwordx8 s[{BASE + 16}:{BASE + 23}], %[wb], {REF} offset:64",
+         f"s_load_dwordx4 s[{BASE + 24}:{BASE + 27}], %[wb], {REF} offset:96",
+         f"s_load_dwordx4 s[{BASE + 28}:{BASE + 31}], %[wb], {REF} offset:112",
+         "s_cmp_gt_u32 %[sp], 59",
+         "s_cbranch_scc1 80f",
+         f"s_mov_b32 {NXREF}, -1",
+         f"s_mov_b64 exec, {M}",
+         "s_waitcnt lgkmcnt(0)"]
+    L += cheap_pair(0, 1, octant)
+    L += cheap_pair(2, 3, octant)
+    L += [f"s_add_u32 {RLO}, {T(0)}, 1"]
+    for k in range(4):
+        L += [f"s_cmp_ge_u32 {T(k) if k else RLO}, %[rb]",
+              f"s_cselect_b64 {H(k)}, 0, {H(k)}"]
+        if k < 3:
+            L += [f"s_cmp_le_u32 {T(k + 1)}, %[ra]",
+                  f"s_cselect_b64 {H(k)}, 0, {H(k)}"]
+    for k in range(4):
+        L += [f"s_cmp_lg_u64 {H(k)}, 0",
+              f"s_cbranch_scc0 2{k}f",
+              f"s_bitcmp1_b32 {N(24 + k)}, 0",
+              f"s_cbranch_scc1 3{k}f",
+              f"s_cmp_eq_u32 {NXREF}, -1",
+              f"s_cbranch_scc0 4{k}f",
+              f"s_mov_b32 {NXREF}, {N(24 + k)}",
+              f"s_mov_b64 {NXM}, {H(k)}",
+              f"2{k}:"]
+    L += [f"s_cmp_eq_u32 {NXREF}, -1",
+          "s_cbranch_scc1 5f",
+          f"s_mov_b32 {REF}, {NXREF}",
+          f"s_andn2_b64 {M}, {NXM}, %[occ]",
+          "s_cbranch_scc1 1b",
+          # ---- pop -----------------------------------------------------------------------------------------------
+          "5:",
+          "s_cmp_eq_u32 %[sp], 0",
+          "s_cbranch_scc1 90f",
+          "s_sub_u32 %[sp], %[sp], 1",
+          "s_mov_b32 m0, %[sp]",
+          f"v_readlane_b32 {REF}, %[vref], m0",
+          f"v_readlane_b32 {MLO}, %[vlo], m0",
+          f"v_readlane_b32 {MHI}, %[vhi], m0",
+          f"s_andn2_b64 {M}, {M}, %[occ]",
+          "s_cbranch_scc0 5b",
+          f"s_bcnt1_i32_b64 {RLO}, {M}",
+          f"s_add_u32 %[acc], %[acc], {RLO}",
+          "s_sub_u32 %[budget], %[budget], 1",
+          "s_cbranch_scc0 1b",
+          # ---- the caller's turn: the node just popped goes back on the stack (and is counted when it is popped again) ------
+          f"s_sub_u32 %[acc], %[acc], {RLO}",
+          "s_mov_b32 m0, %[sp]",
+          f"v_writelane_b32 %[vref], {REF}, m0",
+          f"v_writelane_b32 %[vlo], {MLO}, m0",
+          f"v_writelane_b32 %[vhi], {MHI}, m0",
+          "s_add_u32 %[sp], %[sp], 1",
+          "s_mov_b32 %[budget], 2",
+          "s_branch 99f",
+          # ---- stack nearly full: the current node goes back on the stack, every ray continues alone ---------------------
+          "80:",
+          "s_mov_b32 m0, %[sp]",
+          f"v_writelane_b32 %[vref], {REF}, m0",
+          f"v_writelane_b32 %[vlo], {MLO}, m0",
+          f"v_writelane_b32 %[vhi], {MHI}, m0",
+          "s_add_u32 %[sp], %[sp], 1",
+          "s_mov_b32 %[budget], 1",
+          "s_branch 99f",
+          "90:",
+          "s_mov_b32 %[budget], 0",
+          "s_branch 99f"]
+    for k in range(4):
+        L += [f"4{k}:",
+              "s_mov_b32 m0, %[sp]",
+              f"v_writelane_b32 %[vref], {N(24 + k)}, m0",
+              f"v_writelane_b32 %[vlo], {s(HBASE + 2 * k)}, m0",
+              f"v_writelane_b32 %[vhi], {s(HBASE + 1 + 2 * k)}, m0",
+              "s_add_u32 %[sp], %[sp], 1",
+              f"s_branch 2{k}b"]
+    for k in range(4):
+        L += [f"3{k}:",
+              f"s_cmp_eq_u32 {N(24 + k)}, -1",
+              f"s_cbranch_scc1 2{k}b",
+              f"s_andn2_b64 exec, {H(k)}, %[occ]",
+              f"s_cbranch_scc0 6{k}f",
+              f"s_sub_u32 {REF}, {N(24 + k)}, 1",
+              f"s_load_dwordx8 s[{BASE + 28}:{BASE + 35}], %[tb], {REF}",
+              f"s_load_dword {T(8)}, %[tb], {REF} offset:32",
+              "s_waitcnt lgkmcnt(0)"]
+        L += triangle(R)
+        L += [f"s_andn2_b64 exec, exec, {R}",
+              f"s_cbranch_scc0 6{k}f"]
+        L += exact_box(k, octant, R)
+        L += [f"s_or_b64 %[occ], %[occ], {R}",
+              f"6{k}:",
+              f"s_branch 2{k}b"]
+    L += ["99:",
+          "s_waitcnt lgkmcnt(0)",
+          f"v_readlane_b32 {RLO}, %[vlo], 63",
+          f"v_readlane_b32 {RHI}, %[vhi], 63",
+          f"s_mov_b64 exec, {R}"]
+    return L
+
+
+def emit_range(ind):
+    lines = loop_range()
+    body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
+    outs = ['[sp] "+s"(sp)', '[acc] "+s"(acc)', '[budget] "+s"(budget)', '[occ] "+s"(occ)',
+            '[vref] "+v"(stRef)', '[vlo] "+v"(stLo)', '[vhi] "+v"(stHi)']
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(12)]
+    ins = ['[wb] "s"(wbase)', '[tb] "s"(tbase)', '[ra] "s"(ra)', '[rb] "s"(rb)']
+    ins += [f'[o{a}] "v"(r.o.{a})' for a in AX] + [f'[i{a}] "v"(r.inv.{a})' for a in AX] + [f'[d{a}] "v"(r.d.{a})' for a in AX]
+    ins += ['[tm] "s"(tmax)']
+    ins += [f'[cu{a}] "v"(w.cU.{a})' for a in AX] + [f'[cd{a}] "v"(w.cD.{a})' for a in AX]
+    clob = [f'"s{i}"' for i in range(BASE, BASE + NSGPR)] + ['"vcc"', '"scc"', '"m0"']
+    return (f"{ind}asm volatile(\n{body}\n{ind}    : {', '.join(outs)}\n{ind}    : {', '.join(ins)}\n"
+            f"{ind}    : {', '.join(clob)});\n")
+
+
 def emit(octant, ind):
     lines = loop(octant)
     body = "\n".join(f'{ind}    "{l}\\n\\t"' for l in lines)
@@ -336,7 +469,17 @@ def main():
         o.append(f"    case {octant}:" if octant < 8 else "    default:")
         o.append(emit(octant, "        ").rstrip("\n"))
         o.append("        break;")
-    o += ["    }", "    return acc;", "}", ""]
+    o += ["    }", "    return acc;", "}", "",
+          "// The same walk for a PIECE of a split tile (generic form): pops from the stack the caller prepared, drops the slots whose",
+          "// index range lies outside [ra, rb), and returns after `pops` pops (2), on a full stack (1) or when the stack is empty (0);",
+          "// `acc` keeps adding up the members picked up per pop.",
+          "__device__ __forceinline__ uint32_t wideDescendRange(const void* wbase, const void* tbase, const Ray& r, const WideRay& w, float tmax,",
+          "                                                   uint32_t ra, uint32_t rb, uint64_t& occ, uint32_t& sp, uint32_t& stRef, uint32_t& stLo,",
+          "                                                   uint32_t& stHi, uint32_t& acc, uint32_t pops) {",
+          "    int32_t budget = (int32_t)pops - 1;",
+          "    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11;",
+          emit_range("    ").rstrip("\n"),
+          "    return (uint32_t)budget;", "}", ""]
     open(OUT, "w").write("\n".join(o))
     print("wrote", OUT, sum(1 for _ in open(OUT)), "lines")
 

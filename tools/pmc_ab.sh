@@ -16,8 +16,9 @@ acc = collections.defaultdict(float); n = collections.defaultdict(set)
 for p in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         if "shadowMask" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
+            key = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])       # (per instantiation: a planning launch is another kernel)
+            acc[key] += float(r["Counter_Value"]); n[key].add(r["Dispatch_Id"])
 for k in sorted(acc):
-    print(f"   {k}: {acc[k] / len(n[k]):.0f} per launch ({len(n[k])} launches)")
+    print(f"   {k[0]} {k[1]}: {acc[k] / len(n[k]):.0f} per launch ({len(n[k])} launches)")
 PY
 done
