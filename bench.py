@@ -27,7 +27,8 @@ on every pixel it owns (the correctness gate of SURVEY.md 8d); a mismatch aborts
               factor calibrated in the same pass on a frame whose read volume is known) / launch time / 8 TB/s
   valu_issue  wave64 VALU instructions per launch (SQ_INSTS_VALU, same mechanism) / (launch time x measured shader
               clock x 1024 SIMDs) against 0.5 per clock per SIMD (MI355X_MICROARCH.md: 2 cycles per wave64 VALU op)
-`bound` names the larger fraction.  The cache-oblivious figure of SURVEY.md 8d (32 V + 16 L + 17 bytes per ray) is
+`bound` names the larger fraction; when that is valu_issue the headline `frac` is its USEFUL share, issue fraction x
+lane_fill_members (lanes that hold a ray taking part in the test, counted by the oracle), the raw figure beside it.  The cache-oblivious figure of SURVEY.md 8d (32 V + 16 L + 17 bytes per ray) is
 kept as `algorithmic_*`: it exceeds the HBM peak several times because the packet kernel fetches a node once per wave
 through the scalar cache, so it prices the shader's memory behaviour, not this kernel's.
 """
@@ -94,7 +95,7 @@ def _per_dispatch(csv_dir, kernel_substr="shadowMask"):
     return out
 
 
-def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, options=None):
+def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, options=None, splits=None):
     """Runs `bench.py --pmc-child` under rocprofv3 once per counter group; returns a dict or None."""
     config = config or args.config
     kernel = args.kernel if kernel is None else kernel
@@ -106,7 +107,7 @@ def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, 
     work = tempfile.mkdtemp(prefix="rts_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--kernel", str(kernel),
-             "--options", args.options if options is None else options, "--prewarm-seconds", "0"]
+             "--options", args.options if options is None else options, "--splits", splits_arg(splits), "--prewarm-seconds", "0"]
     res = {"source": "live: rocprofv3 --pmc child passes of this command in this run", "passes": []}
     t_all = time.time()
     try:
@@ -119,6 +120,7 @@ def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, 
             return None
         manifest = json.loads(r.stdout.strip().splitlines()[-1])
         n_cal, n_pre, n_real = manifest["calib_launches"], manifest["prewarm_launches"], manifest["real_launches"]
+        n_plan = manifest.get("plan_launches", 0)               # (planning a split table: statistics + planning walk, other instantiations)
         durs = []
         for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             with open(path, newline="") as fh:
@@ -126,10 +128,10 @@ def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, 
                     if "shadowMask" in row.get("Kernel_Name", ""):
                         durs.append((int(row["Dispatch_Id"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), row))
         durs.sort(key=lambda t: t[0])
-        if len(durs) != n_cal + n_pre + n_real:
-            say(f"kernel trace has {len(durs)} shadow dispatches, expected {n_cal + n_pre + n_real}: no live counters")
+        if len(durs) != n_cal + n_plan + n_pre + n_real:
+            say(f"kernel trace has {len(durs)} shadow dispatches, expected {n_cal + n_plan + n_pre + n_real}: no live counters")
             return None
-        real = [t[1] for t in durs[n_cal + n_pre:]]
+        real = [t[1] for t in durs[-n_real:]]
         row = durs[-1][2]
         res["kernel_trace"] = {"kernel": row["Kernel_Name"], "launches": n_real, "avg_ns": sum(real) / len(real),
                                "median_ns": sorted(real)[len(real) // 2],
@@ -146,14 +148,16 @@ def live_counters(args, say, config=None, kernel=None, passes=None, trace=True, 
                 continue
             per = _per_dispatch(d)
             for name, vals in per.items():
-                if len(vals) != n_cal + n_real:                 # (the counter passes run without a pre-warm)
+                if len(vals) != n_cal + n_plan + n_real:        # (the counter passes run without a pre-warm)
                     continue
                 calib[name] = sum(vals[:n_cal]) / n_cal
-                counters[name] = sum(vals[n_cal:]) / n_real
+                counters[name] = sum(vals[-n_real:]) / n_real
             res["passes"].append(group)
         res["counters_per_launch"] = counters
         res["calibration_counters_per_launch"] = calib
         res["calibration"] = manifest["calibration"]
+        if manifest.get("split_table"):
+            res["split_table_under_the_profiler"] = manifest["split_table"]
         res["seconds"] = round(time.time() - t_all, 1)
         return res if counters else None
     except Exception as e:                                    # a profiler problem must never cost the benchmark line
@@ -231,6 +235,22 @@ def roofline_bounds(counters, avg_launch_s, clock_mhz):
     return roof
 
 
+def headline_fraction(roof, lane_fill_members):
+    """the headline `frac` is the USEFUL share of the VALU peak -- issue fraction x the share of lanes that hold a ray
+    taking part in the test (counted by the oracle for the same frame) -- so that a kernel which does the same work in fewer
+    instructions cannot score lower; the raw issue fraction stays beside it.  Pure arithmetic (tests/test_host_logic.py)."""
+    if roof.get("bound") != "valu_issue" or not roof.get("valu_issue") or not lane_fill_members:
+        return roof
+    raw = roof["valu_issue"]["frac"]
+    roof["frac_valu_issue_raw"] = raw
+    roof["lane_fill_members"] = lane_fill_members
+    roof["frac"] = round(raw * lane_fill_members, 4)
+    roof["achieved"] = round(roof["valu_issue"]["achieved"] * lane_fill_members, 4)
+    roof["unit"] = "useful wave64 VALU instr / clk / SIMD (issue rate x lanes that hold a participating ray)"
+    roof["frac_definition"] = "valu_issue.frac x lane_fill_members"
+    return roof
+
+
 def pmc_child(args):
     """The command the profiler passes run: a few launches on the calibration frame (1-triangle BVH: the read volume is
     the position stream, known), then on the real one.  Prints a one-line manifest."""
@@ -251,6 +271,10 @@ def pmc_child(args):
             ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
         ctx.synchronize()
         ctx.set_bvh(wl.packed)
+        n_plan, table = 0, None
+        if args.splits:                                          # the split table of the tuning child, planned again here
+            table = apply_splits(ctx, args.splits, wl, d_pos, d_mask)
+            n_plan = 3 if table else 2                           # 2 launches with wave statistics (+ the planning walk)
         n_pre = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < args.prewarm_seconds:   # only the kernel-trace pass asks for one (durations)
@@ -265,6 +289,7 @@ def pmc_child(args):
         ctx.free(d_pos)
         ctx.free(d_mask)
     print(json.dumps({"calib_launches": n_cal, "prewarm_launches": n_pre, "real_launches": n_real, "kernel": kname,
+                      "plan_launches": n_plan, "split_table": table,
                       "calibration": {"known_read_bytes": W * H * 16 + 48, "known_write_bytes": W * H,
                                       "what": "same frame and light, BVH of one far-away triangle: reads = the position stream"}}))
 
@@ -316,9 +341,12 @@ def tune_child(args):
         ctx.synchronize()
         chosen, ms = ctx.autotune(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light)
         tuned = {k: ctx.get_option(k) for k in TUNED_OPTIONS}
+        plan = ctx.split_plan()                                 # the split table the third stage kept (None: the plain launch won)
+        if plan:
+            plan.update(table_size(ctx))
         ctx.free(d_pos)
         ctx.free(d_mask)
-    print(json.dumps({"kernel": chosen, "ms": ms, "options": tuned}))
+    print(json.dumps({"kernel": chosen, "ms": ms, "options": tuned, "splits": plan}))
 
 
 TUNED_OPTIONS = ("packet_share", "row_order")       # what rts_ctx_autotune sets besides the kernel
@@ -328,6 +356,40 @@ def options_arg(options):
     return ",".join(f"{k}={v}" for k, v in sorted((options or {}).items()))
 
 
+def splits_arg(plan):
+    """A split plan (dict of rts_split_plan's numbers) as command-line text for the child processes; '' = no table."""
+    if not plan:
+        return ""
+    return (":".join(repr(float(plan.get(k, 0.0))) for k in ("min_life_us", "end_after_us", "piece_us", "front_life_us", "front_share"))
+            + f":{int(plan['max_pieces'])}:{int(plan.get('max_tiles', 0))}")
+
+
+def parse_splits(text):
+    if not text:
+        return None
+    f = text.split(":")
+    return {"min_life_us": float(f[0]), "end_after_us": float(f[1]), "piece_us": float(f[2]), "front_life_us": float(f[3]),
+            "front_share": float(f[4]), "max_pieces": int(f[5]), "max_tiles": int(f[6])}
+
+
+def apply_splits(ctx, plan, wl, d_pos, d_mask, stripes=None):
+    """Plans the table on this process's device with the tuning child's parameters; returns {tiles, pieces} or None."""
+    plan = parse_splits(plan) if isinstance(plan, str) else plan
+    if not plan:
+        return None
+    tiles, records = ctx.plan_splits(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, min_life_us=plan["min_life_us"],
+                                     end_after_us=plan["end_after_us"], piece_us=plan["piece_us"], max_pieces=plan["max_pieces"],
+                                     front_life_us=plan.get("front_life_us", 0.0), front_share=plan.get("front_share", 0.0),
+                                     max_tiles=plan.get("max_tiles", 0), stripes=stripes)
+    return table_size(ctx) if tiles else None
+
+
+def table_size(ctx):
+    """What the installed split table holds: tiles split into pieces, their pieces, long tiles merely started first."""
+    front = ctx.get_option("front_tiles")
+    return {"split_tiles": ctx.get_option("split_tiles"), "pieces": ctx.get_option("split_pieces") - front, "front_tiles": front}
+
+
 def apply_options(ctx, text):
     for kv in filter(None, (text or "").split(",")):
         k, v = kv.split("=")
@@ -335,19 +397,19 @@ def apply_options(ctx, text):
 
 
 def pick_kernel(args, config, say):
-    """(kernel id, launch options) for `config`: the caller's --kernel / --options, else the autotuner's choice (a child process:
-    this one must not touch the GPU before the profiler passes have run)."""
+    """(kernel id, launch options, split plan) for `config`: the caller's --kernel / --options / --splits, else the autotuner's
+    choice (a child process: this one must not touch the GPU before the profiler passes have run)."""
     if args.kernel >= 0:
-        return args.kernel, args.options
+        return args.kernel, args.options, parse_splits(args.splits)
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tune-child", "--config", config], cwd="/tmp",
                            capture_output=True, text=True, timeout=300)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
-        say(f"autotune [{config}]: kernel {rec['kernel']}, {rec.get('options')} ({rec['ms']:.4f} ms)")
-        return int(rec["kernel"]), options_arg(rec.get("options"))
+        say(f"autotune [{config}]: kernel {rec['kernel']}, {rec.get('options')}, split table {rec.get('splits')} ({rec['ms']:.4f} ms)")
+        return int(rec["kernel"]), options_arg(rec.get("options")), rec.get("splits")
     except Exception as e:
         say(f"autotune child failed for {config} ({e!r}): library default")
-        return -1, args.options
+        return -1, args.options, None
 
 
 def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=0):
@@ -361,8 +423,6 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
         prewarm_launches += 50
     for _ in range(warmup):
         step()
-    if probe_rows:
-        ctx.set_option("clock_probe", probe_rows)                # the timed launches stamp their own clock
     if barrier:
         barrier()
     ctx.synchronize()
@@ -378,7 +438,13 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
     per_launch = np.array([ctx.timer_between_ms(i, i + 1) for i in range(steps)])   # HIP events, launch stream
     clock = None
     if probe_rows:
+        # the shader clock from a probed run of the same launch RIGHT AFTER the timed region (the probe -- one wave per tile row
+        # stamping both clocks -- is not part of the launches that are timed)
+        ctx.set_option("clock_probe", probe_rows)
         try:
+            for _ in range(max(10, min(steps, 50))):
+                step()
+            ctx.synchronize()
             clock = ctx.clock_probe_mhz(probe_rows)
         finally:
             ctx.set_option("clock_probe", 0)
@@ -418,6 +484,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = what rts_ctx_autotune picks for the frame)")
     ap.add_argument("--options", default="", help="context options for the traced frame, key=value,... (with --kernel; else what "
                                                   "rts_ctx_autotune picks: packet_share, row_order)")
+    ap.add_argument("--splits", default="", help="split table for the traced frame, min_life_us:end_after_us:piece_us:front_life_us:front_share:max_pieces:max_tiles (with "
+                                                 "--kernel; else what rts_ctx_autotune keeps)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -492,15 +560,15 @@ def main():
 
     # ---- kernel choice and counters, by child processes while this one has not touched the GPU yet ----------------
     secondary_names = [] if (N > 1 or args.no_secondary) else SECONDARY.get(args.config, [])
-    kernel_id, kernel_opts = pick_kernel(args, args.config, say) if N == 1 else (args.kernel, args.options)
+    kernel_id, kernel_opts, split_plan = pick_kernel(args, args.config, say) if N == 1 else (args.kernel, args.options, parse_splits(args.splits))
     counters = None
     if N == 1 and not args.no_pmc:
-        counters = live_counters(args, say, kernel=kernel_id, options=kernel_opts)
+        counters = live_counters(args, say, kernel=kernel_id, options=kernel_opts, splits=split_plan)
     secondary_plan = []
     for name in secondary_names:
-        kid, kopts = pick_kernel(args, name, say)
-        cnt = None if args.no_pmc else live_counters(args, say, config=name, kernel=kid, passes=PMC_PASSES_SECONDARY, options=kopts)
-        secondary_plan.append((name, kid, cnt, kopts))
+        kid, kopts, ksplits = pick_kernel(args, name, say)
+        cnt = None if args.no_pmc else live_counters(args, say, config=name, kernel=kid, passes=PMC_PASSES_SECONDARY, options=kopts, splits=ksplits)
+        secondary_plan.append((name, kid, cnt, kopts, ksplits))
 
     my_rows = partition.stripe_rows(H, N, rank, band=BAND, interleaved=True) if striped else [(0, H)]
     my_rays = sum(e - b for b, e in my_rows) * W * max(1, spp)
@@ -526,13 +594,27 @@ def main():
     d_mask = ctx.malloc(W * H)
     ctx.h2d(d_pos, wl.positions)
     ctx.h2d(d_mask, np.zeros((H, W), np.uint8))
-    if N > 1 and args.kernel < 0:                               # every rank tunes on its own device (the full frame, untimed)
-        kernel_id, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
-        # (a stripe is launched in row order whatever "row_order" says; the dissolve threshold is kept)
+    my_stripes = (BAND, N, rank) if striped else None
+    split_table = None
+    if N > 1 and args.kernel < 0:
+        # every rank tunes WHAT IT RUNS, on its own device (untimed): the dispatch of its own stripe -- kernel, dissolve
+        # threshold and the split table for its rows (rts_ctx_autotune_stripes); a frame per rank (--scaling weak): the frame
+        for _ in range(100):
+            if striped:
+                ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, BAND, N, rank, light=wl.light)
+            else:
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        ctx.synchronize()
+        kernel_id, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light, stripes=my_stripes)
         kernel_opts = options_arg({k: ctx.get_option(k) for k in TUNED_OPTIONS})
-    if kernel_id >= 0:
-        ctx.set_option("kernel", kernel_id)
-    apply_options(ctx, kernel_opts)
+        split_plan = ctx.split_plan()
+        if split_plan:
+            split_table = table_size(ctx)
+    else:
+        if kernel_id >= 0:
+            ctx.set_option("kernel", kernel_id)
+        apply_options(ctx, kernel_opts)
+        split_table = apply_splits(ctx, split_plan, wl, d_pos, d_mask, stripes=my_stripes)
 
     def one_step(c=ctx):                  # ONE dispatch per step on every rank
         if striped:
@@ -623,13 +705,14 @@ def main():
         g2 = [torch.zeros_like(t2) for _ in range(N)]
         dist.all_gather(g2, t2)
         wall2 = max(float(x[0]) for x in g2)
-        t = torch.tensor([wall, kernel_ms, median_ms, floor_ms], dtype=torch.float64)
+        t = torch.tensor([wall, kernel_ms, median_ms, floor_ms, float(kernel_id), float(ctx.get_option("packet_share")),
+                          float(split_table["split_tiles"] if split_table else 0), float(split_table["front_tiles"] if split_table else 0)], dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(N)]
         dist.all_gather(gathered, t)
         per_rank = [[float(x) for x in g] for g in gathered]
         wall = max(g[0] for g in per_rank)                          # MAX over ranks
     else:
-        per_rank = [[wall, kernel_ms, median_ms, floor_ms]]
+        per_rank = [[wall, kernel_ms, median_ms, floor_ms, float(kernel_id), 0.0, 0.0, 0.0]]
 
     frames_per_step = N if (args.scaling == "weak" and N > 1) else 1
     total_rays = rays_per_frame * frames_per_step * args.steps
@@ -646,8 +729,10 @@ def main():
                                + ("one frame per GPU" if frames_per_step > 1 else
                                   f"one frame row-striped over {N} GPUs in interleaved {BAND}-row bands" if striped else "one frame"),
                    "rays_per_frame": rays_per_frame, "kernel": kname,
-                   "kernel_choice": "--kernel" if args.kernel >= 0 else "rts_ctx_autotune on this frame (untimed set-up)",
+                   "kernel_choice": "--kernel" if args.kernel >= 0 else ("rts_ctx_autotune on this frame (untimed set-up)" if N == 1 else
+                                                                          "rts_ctx_autotune_stripes: every rank on its own stripe's dispatch (untimed set-up)"),
                    "launch_options": kernel_opts,
+                   "split_table": dict(split_table, plan=split_plan) if split_table else None,
                    "bvh_bytes": int(wl.packed.nbytes),
                    "ms_per_frame_gpu_median": round(max(g[2] for g in per_rank), 4),
                    "ms_per_frame_gpu_mean": round(max(g[1] for g in per_rank) / args.steps, 4),
@@ -662,7 +747,9 @@ def main():
                     "overlap: one frame's tail beside the next frame's bulk); `value` above is one frame at a time"}
     if N > 1:
         result["config"]["per_rank"] = [{"rank": r, "device": ordinals[r], "wall_ms_per_step": round(g[0] / args.steps * 1e3, 4),
-                                         "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": None if args.no_probes else round(g[3], 4)}
+                                         "gpu_median_ms": round(g[2], 4), "dispatch_floor_ms": None if args.no_probes else round(g[3], 4),
+                                         "tuned_on_its_own_stripe": {"kernel": int(g[4]), "packet_share": int(g[5]),
+                                                                     "split_tiles": int(g[6]), "front_tiles": int(g[7])}}
                                         for r, g in enumerate(per_rank)]
 
     # ---- roofline (N = 1) -------------------------------------------------------------------------------------------
@@ -670,7 +757,8 @@ def main():
             "algorithmic_GBps": round(alg_bytes_per_step / avg_launch_s / 1e9, 1),
             "avg_launch_ms": round(avg_launch_s * 1e3, 5), "median_launch_ms": round(median_ms, 5), "kernel": kname,
             "shader_clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
-            "shader_clock_source": "stamps of the timed launches themselves (first wave of every tile row)" if clock_mhz else None,
+            "shader_clock_source": "stamps of 10-50 launches of the same dispatch right after the timed region (first wave of every tile row); "
+                                   "the timed launches carry no probe" if clock_mhz else None,
             "note": "frac = the larger of two measured bounds (see the module docstring); algorithmic_* is SURVEY 8d's "
                     "cache-oblivious 32V+16L+17 B/ray from the oracle's exact visit counts, informational; packet_bytes is the same "
                     "model at the granularity this kernel fetches at (once per wave), a fraction of the HBM peak <= 1"}
@@ -690,6 +778,7 @@ def main():
             roof["packet_bytes"] = pm
             if roof.get("valu_issue"):
                 roof["valu_issue"]["lane_fill_members"] = pm["lane_fill_members"]
+            headline_fraction(roof, pm["lane_fill_members"])
         except Exception as e:
             say(f"packet model failed: {e!r}")
     result["roofline"] = roof
@@ -726,7 +815,7 @@ def main():
     # ---- the other workloads (N = 1): the same protocol -- parity gate on every pixel, pre-warm, 20 timed steps -- no CPU
     #      baseline; their counters come from their own profiler passes (above) --------------------------------------------
     secondary = {}
-    for name, kid, cnt, kopts in secondary_plan:
+    for name, kid, cnt, kopts, ksplits in secondary_plan:
         try:
             t_start = time.time()
             swl = workloads.prepare_config(name, cache=True, threads=host_threads, log=say)
@@ -738,6 +827,7 @@ def main():
             apply_options(sctx, kopts)
             sd_pos, sd_mask = sctx.malloc(swl.positions.nbytes), sctx.malloc(sW * sH)
             sctx.h2d(sd_pos, swl.positions)
+            stable = apply_splits(sctx, ksplits, swl, sd_pos, sd_mask)
 
             def sstep():
                 sctx.trace_shadow_mask_device(swl.constants, sd_pos, sW, sH, sd_mask, light=swl.light)
@@ -748,7 +838,7 @@ def main():
             sm = measure(sctx, sstep, 20, 5, args.prewarm_seconds, probe_rows=((sH + 7) // 8) if spacket else 0)
             s_avg = sm["kernel_ms"] / 1e3 / 20
             rec = {"workload": f"{name}: {workloads.CONFIGS[name][0]} ({swl.prim_count} triangles), {sW}x{sH}, {max(1, swl.spp)} spp",
-                   "kernel": sk, "launch_options": kopts, "parity": f"{swl.rays} rays bit-exact vs the oracle", "steps": 20, "warmup": 5,
+                   "kernel": sk, "launch_options": kopts, "split_table": dict(stable, plan=ksplits) if stable else None, "parity": f"{swl.rays} rays bit-exact vs the oracle", "steps": 20, "warmup": 5,
                    "value": round(swl.rays * 20 / sm["wall"] / 1e6, 1), "unit": "Mrays/s",
                    "ms_per_frame_gpu_median": round(sm["median_ms"], 4),
                    "nodes_per_ray": round(sV / swl.rays, 2), "triangle_tests_per_ray": round(sL / swl.rays, 2),
@@ -764,6 +854,8 @@ def main():
                 rec["packet_bytes"] = pm
                 if rec.get("valu_issue"):
                     rec["valu_issue"]["lane_fill_members"] = pm["lane_fill_members"]
+                    if rec.get("bound") == "valu_issue":
+                        rec["frac_valu_issue_raw"], rec["frac"] = rec["frac"], round(rec["frac"] * pm["lane_fill_members"], 4)
             rec["seconds"] = round(time.time() - t_start, 1)
             secondary[name] = rec
             say(f"secondary [{name}]: {rec['value']} Mrays/s, {rec['ms_per_frame_gpu_median']} ms ({sk})")

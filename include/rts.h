@@ -291,6 +291,11 @@ typedef struct rts_split_plan {
     float    end_after_us;       /* >= 0: ... and only the tiles whose wave ENDED later than this after the dispatch's first wave
                                     started (the waves that end last are the dispatch's tail; 0 = every long tile) */
     float    piece_us;           /* > 0 */
+    float    front_life_us;      /* 0, or < min_life_us: the tiles that lived longer than this but are not split are FRONT tiles -- walked
+                                    by their own wave, unchanged, but dispatched at the head of the grid (after the pieces, longest
+                                    first): what is long starts early, and the dispatch ends with short waves */
+    float    front_share;        /* 0..1: ... or, given as a share: the longest front_share of all tiles of the dispatch start first (the
+                                    larger of the two thresholds counts when both are given; a third is what rts_ctx_autotune tries) */
     uint32_t max_pieces;         /* 2..64 */
     uint32_t max_tiles;          /* 0 = 4096 */
     const uint64_t* prev_stats;  /* all three NULL / 0: measure now */

@@ -55,7 +55,7 @@ struct rts_ctx {
         uint32_t W = 0, H = 0, rowBegin = 0, rowEnd = 0, bandRows = 0, nStripes = 0, stripe = 0, blocksX = 0, blocksY = 0;
         uint32_t* d_skipMap = nullptr;       // one bit per tile of the dispatch
         uint32_t* d_pieces = nullptr;        // 8 dwords per piece
-        uint32_t nPieces = 0, pieceRows = 0, nTiles = 0;
+        uint32_t nPieces = 0, pieceRows = 0, nTiles = 0, nFront = 0;      // records (pieces + front tiles), split tiles, front tiles
         rts_split_plan plan{};               // what the table was planned with (rts_ctx_get_split_plan)
         // {occluded lanes, pieces done} per split tile: one buffer per stream that traces with the table, so that frames in
         // flight on different streams never meet in it (frames on one stream follow each other)
@@ -359,6 +359,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { *value = c->useSplits; return RTS_OK; }
     if (!strcmp(key, "split_tiles")) { *value = c->splits.valid ? (int)c->splits.nTiles : 0; return RTS_OK; }
+    if (!strcmp(key, "front_tiles")) { *value = c->splits.valid ? (int)c->splits.nFront : 0; return RTS_OK; }
     if (!strcmp(key, "split_pieces")) { *value = c->splits.valid ? (int)c->splits.nPieces : 0; return RTS_OK; }
     if (!strcmp(key, "wide_levels")) { *value = (int)c->wideLevels; return RTS_OK; }
     return RTS_ERR_INVALID_ARG;
@@ -711,7 +712,8 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
                           const rts_split_plan* plan, uint32_t* tiles_out, uint32_t* pieces_out) {
     if (tiles_out) *tiles_out = 0;
     if (pieces_out) *pieces_out = 0;
-    if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f) || !(plan->end_after_us >= 0.f))
+    if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f) || !(plan->end_after_us >= 0.f) ||
+        !(plan->front_life_us >= 0.f) || plan->front_life_us > plan->min_life_us || !(plan->front_share >= 0.f) || plan->front_share > 1.f)
         return RTS_ERR_INVALID_ARG;
     if (light && light->nsamples > 1) return RTS_ERR_INVALID_ARG;               // (soft shadows are dealt over waves by "soft_split")
     RTS_HIP(hipSetDevice(c->device));
@@ -757,24 +759,40 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         }
         // the tiles whose wave lived longer than min_life_us, longest first
         struct Sel { float us; uint32_t tile; };
-        std::vector<Sel> sel;
+        std::vector<Sel> sel, front;                                            // to be split / to be started first, unsplit
         const uint32_t blocksX = (W + 7) / 8;
         uint32_t blocksY = 0;
         uint64_t began = ~0ull;                                                 // the dispatch's first wave
         for (size_t i = 0; i < waves; ++i) if (rt[i * 4 + 1] > rt[i * 4] && rt[i * 4] < began) began = rt[i * 4];
+        float frontLife = plan->front_life_us;
+        if (plan->front_share > 0.f) {                                           // the life the longest front_share of the tiles exceed
+            std::vector<float> lives;
+            lives.reserve(waves);
+            for (size_t i = 0; i < waves; ++i) if (rt[i * 4 + 1] > rt[i * 4]) lives.push_back((float)(rt[i * 4 + 1] - rt[i * 4]) * 0.01f);
+            if (!lives.empty()) {
+                size_t nth = (size_t)((1.0 - (double)plan->front_share) * (double)lives.size());
+                if (nth >= lives.size()) nth = lives.size() - 1;
+                std::nth_element(lives.begin(), lives.begin() + nth, lives.end());
+                if (lives[nth] > frontLife) frontLife = lives[nth];
+            }
+        }
         for (size_t i = 0; i < waves; ++i) {
             const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
             if (r1 <= r0) continue;
             const float us = (float)(r1 - r0) * 0.01f;
-            if ((float)(r1 - began) * 0.01f <= plan->end_after_us) continue;
             const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
             if (by >= blocksY) blocksY = by + 1;
-            if (us > plan->min_life_us && bx < blocksX) sel.push_back({ us, bx | (by << 16) });
+            if (bx >= blocksX) continue;
+            if (us > plan->min_life_us && (float)(r1 - began) * 0.01f > plan->end_after_us) sel.push_back({ us, bx | (by << 16) });
+            else if (frontLife > 0.f && us > frontLife) front.push_back({ us, bx | (by << 16) });
         }
-        if (sel.empty()) return RTS_OK;
-        std::sort(sel.begin(), sel.end(), [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); });
-        if (sel.size() > maxTiles) sel.resize(maxTiles);
-        const uint32_t T = (uint32_t)sel.size();
+        if (sel.empty() && front.empty()) return RTS_OK;
+        const auto longer = [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); };
+        std::sort(sel.begin(), sel.end(), longer);
+        std::sort(front.begin(), front.end(), longer);
+        if (sel.size() > maxTiles) { front.insert(front.begin(), sel.begin() + maxTiles, sel.end()); sel.resize(maxTiles); }   // (what is not split starts first at least)
+        if (front.size() > 262144) front.resize(262144);
+        const uint32_t T = (uint32_t)sel.size(), F = (uint32_t)front.size();
         std::vector<rts::SplitCut> cuts(T);
         std::vector<uint32_t> first(T), provisional((size_t)T * 8, 0u);
         uint32_t nPieces = 0;
@@ -793,27 +811,31 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         const uint32_t keyBlocksY = (rows + 7) / 8;
         if (blocksY > keyBlocksY) return RTS_ERR_INVALID_ARG;                     // statistics of another dispatch
         std::vector<uint32_t> bitmap(((size_t)blocksX * keyBlocksY + 31) / 32 + 1, 0u);
-        for (uint32_t t = 0; t < T; ++t) {
-            const uint32_t id = (sel[t].tile >> 16) * blocksX + (sel[t].tile & 0xFFFFu);
+        std::vector<uint32_t> frontRecords((size_t)F * 8, 0u);                   // {tile, 0, END, 0 = "front tile", 0...}
+        for (uint32_t t = 0; t < T + F; ++t) {
+            const uint32_t tile = t < T ? sel[t].tile : front[t - T].tile;
+            const uint32_t id = (tile >> 16) * blocksX + (tile & 0xFFFFu);
             bitmap[id >> 5] |= 1u << (id & 31u);
+            if (t >= T) { frontRecords[(size_t)(t - T) * 8] = tile; frontRecords[(size_t)(t - T) * 8 + 2] = 0xFFFFFFFFu; }
         }
         // device side: planning walk of the selected tiles (one piece each, everything logged), then the quantiles
         void *d_cuts = nullptr, *d_first = nullptr, *d_prov = nullptr, *d_log = nullptr, *d_state = nullptr, *d_pieces = nullptr, *d_map = nullptr;
-        const size_t logBytes = (size_t)T * (logCap + 1) * 4;
-        hipError_t e = hipMalloc(&d_cuts, (size_t)T * 8);
-        if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)T * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_prov, (size_t)T * 32);
+        const size_t logBytes = (size_t)T * (logCap + 1) * 4 + 16;
+        hipError_t e = hipMalloc(&d_cuts, (size_t)T * 8 + 16);
+        if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)T * 4 + 16);
+        if (e == hipSuccess) e = hipMalloc(&d_prov, (size_t)T * 32 + 16);
         if (e == hipSuccess) e = hipMalloc(&d_log, logBytes);
-        if (e == hipSuccess) e = hipMalloc(&d_state, (size_t)T * 16);
-        if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)nPieces * 32);
+        if (e == hipSuccess) e = hipMalloc(&d_state, (size_t)T * 16 + 16);
+        if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)(nPieces + F) * 32 + 16);
+        if (e == hipSuccess && F) e = hipMemcpy((char*)d_pieces + (size_t)nPieces * 32, frontRecords.data(), (size_t)F * 32, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&d_map, bitmap.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(d_cuts, cuts.data(), (size_t)T * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_first, first.data(), (size_t)T * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_prov, provisional.data(), (size_t)T * 32, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_map, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(d_log, 0, logBytes);
-        if (e == hipSuccess) e = hipMemset(d_state, 0, (size_t)T * 16);
-        if (e == hipSuccess) {
+        if (e == hipSuccess) e = hipMemset(d_state, 0, (size_t)T * 16 + 16);
+        if (e == hipSuccess && T) {
             const rts_ctx::Planning pl{ (const uint32_t*)d_prov, T, (T + blocksX - 1) / blocksX, (uint64_t*)d_state, (uint32_t*)d_log, logCap };
             c->planning = &pl;
             status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
@@ -838,10 +860,10 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         t.W = W; t.H = H; t.rowBegin = row_begin; t.rowEnd = row_end; t.bandRows = band_rows; t.nStripes = n_stripes; t.stripe = stripe;
         t.blocksX = blocksX; t.blocksY = keyBlocksY;
         t.d_skipMap = (uint32_t*)d_map; t.d_pieces = (uint32_t*)d_pieces;
-        t.nPieces = nPieces; t.pieceRows = (nPieces + blocksX - 1) / blocksX; t.nTiles = T;
+        t.nPieces = nPieces + F; t.pieceRows = (nPieces + F + blocksX - 1) / blocksX; t.nTiles = T; t.nFront = F;
         t.plan = *plan; t.plan.prev_stats = nullptr; t.plan.prev_realtime = nullptr; t.plan.prev_waves = 0;
-        if (tiles_out) *tiles_out = T;
-        if (pieces_out) *pieces_out = nPieces;
+        if (tiles_out) *tiles_out = T + F;
+        if (pieces_out) *pieces_out = nPieces + F;
     } catch (...) {
         c->planning = nullptr;
         return RTS_ERR_CAPACITY;                       // no exception crosses the C ABI
@@ -916,18 +938,27 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
         }
         // third stage: split tables.  Tiles that lived longer than a share of the dispatch and ended in its later part.
         if (c->wideCount && c->blockWaves == 1 && !c->wideLane && (!light || light->nsamples <= 1) && c->useSplits) {
+            // Three tables (profiles/r04/front_tiles_sweep.log): the longest third of the tiles started first and the tiles that lived
+            // longer than a quarter of the dispatch (and 20 us) split into pieces of a tenth of it; the front tiles alone; the splits
+            // alone with a lower threshold.
             const float T = bestMs * 1000.f;                                      // us
-            const float trial[2][2] = { { 0.5f, 0.15f }, { 0.75f, 0.10f } };      // {ended after this share of T, lived longer than this share}
+            const int trials = 3;
             int kept = -1, installed = -1;
             rts_split_plan plan{};
             auto fill = [&](int i) {
                 plan = rts_split_plan{};
-                plan.end_after_us = trial[i][0] * T;
-                plan.min_life_us = trial[i][1] * T < 8.f ? 8.f : trial[i][1] * T;
-                plan.piece_us = plan.min_life_us * 0.5f;
                 plan.max_pieces = 8;
+                plan.max_tiles = 8192;
+                if (i == 0) {
+                    plan.min_life_us = 0.25f * T < 20.f ? 20.f : 0.25f * T; plan.end_after_us = 0.5f * T;
+                    plan.piece_us = 0.1f * T < 8.f ? 8.f : 0.1f * T; plan.front_share = 1.f / 3.f;
+                } else if (i == 1) {
+                    plan.min_life_us = 1e9f; plan.piece_us = 1e9f; plan.front_share = 1.f / 3.f;
+                } else {
+                    plan.min_life_us = 0.15f * T < 8.f ? 8.f : 0.15f * T; plan.end_after_us = 0.5f * T; plan.piece_us = plan.min_life_us * 0.5f;
+                }
             };
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < trials; ++i) {
                 fill(i);
                 uint32_t tiles = 0;
                 status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, &tiles, nullptr);

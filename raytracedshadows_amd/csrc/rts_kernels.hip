@@ -1323,8 +1323,9 @@ __device__ __forceinline__ void runPiece(const TraceParams& p, uint32_t* lds) {
 // a band is 2^bandShift tile rows, so the frame row of a tile row is two shifts and a multiply on the scalar unit
 // instead of the general prologue with its per-lane division.
 // TILESPLIT (with PLAIN, one sample): the launch carries a split table (rts_ctx_plan_splits).  The first pieceRows rows of the
-// grid are PIECES of the tiles measured to be long (traversePiece; dispatched first, so the longest work starts first); the
-// remaining rows are the everyday tile waves, of which those of a split tile end after one bitmap look-up.
+// grid are its records, dispatched first, so that the longest work starts first: PIECES of the tiles measured to be very long
+// (traversePiece), then FRONT tiles -- long tiles that are not worth splitting, walked by their own wave as ever, only early.
+// The remaining rows are the everyday tile waves, of which those of a tile of the table have nothing to do (one bitmap look-up).
 template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false,
           bool TILESPLIT = false>
 // (Registers: a SIMD holds 8 waves of a kernel only up to 64 VGPRs AND 80 SGPRs including VCC / FLAT_SCRATCH / XNACK: the
@@ -1358,13 +1359,20 @@ void shadowMaskPacketKernel(TraceParams p) {
     if constexpr (TILESPLIT) {
         const uint32_t pieceRows = p.pieceRows, blocksX = p.blocksX, blocksY = p.blocksY, rowOrder = p.rowOrder;
         const uint64_t mapAddr = uniform64(p.skipMap);
-        if (blockIdx.y < pieceRows) { runPiece<BANDS>(p, lds); return; }        // a piece of a split tile: a path of its own
-        const uint32_t k = blockIdx.y - pieceRows;
-        by = rowOrder == 1u ? blocksY - 1u - k : (rowOrder == 2u ? ((k & 1u) ? (blocksY >> 1) - ((k + 1u) >> 1) : (blocksY >> 1) + (k >> 1)) : k);
-        // the tile's bit of the split table (the word travels with the next batch of kernel arguments)
-        const uint32_t bit = by * blocksX + bx;
-        const uint32_t word = *(ConstU32Ptr)(uintptr_t)(mapAddr + (uint64_t)(bit >> 5) * 4u);
-        mine = !((word >> (bit & 31u)) & 1u);                        // a split tile is walked by its pieces: nobody is live here
+        if (blockIdx.y < pieceRows) {                                 // the head of the grid: records of the split table
+            const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x;
+            if (id >= p.nPieces) return;
+            const u32x4 rec = *(ConstVec4Ptr)(uintptr_t)(uniform64(p.pieces) + (uint64_t)id * 32u);
+            if (rec.w >> 24) { runPiece<BANDS>(p, lds); return; }     // a piece of a split tile: a path of its own
+            bx = rec.x & 0xFFFFu; by = rec.x >> 16;                   // a FRONT tile: a long tile's own wave, started first
+        } else {
+            const uint32_t k = blockIdx.y - pieceRows;
+            by = rowOrder == 1u ? blocksY - 1u - k : (rowOrder == 2u ? ((k & 1u) ? (blocksY >> 1) - ((k + 1u) >> 1) : (blocksY >> 1) + (k >> 1)) : k);
+            // the tile's bit of the split table (the word travels with the next batch of kernel arguments)
+            const uint32_t bit = by * blocksX + bx;
+            const uint32_t word = *(ConstU32Ptr)(uintptr_t)(mapAddr + (uint64_t)(bit >> 5) * 4u);
+            mine = !((word >> (bit & 31u)) & 1u);                    // a tile of the table is walked by its record(s) at the head
+        }
     } else by = dispatchRow(p, blockIdx.y);                           // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1401,7 +1409,8 @@ void shadowMaskPacketKernel(TraceParams p) {
     // clock probe (every instantiation, so that the clock is measured on the launches that are timed): one wave per tile row
     // (the stamps go straight to memory: nothing of the probe stays in registers across the walk)
     const uint32_t probeRow = TILESPLIT ? blockIdx.y - p.pieceRows : (p.grid2d ? blockIdx.y : 0u);   // (read under p.clockProbe only)
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool probed = p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && (!TILESPLIT || blockIdx.y >= p.pieceRows);
+    if (probed) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1444,7 +1453,7 @@ void shadowMaskPacketKernel(TraceParams p) {
         for (int k = 0; k < K; ++k)
             if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
     }
-    if (p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (probed) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -522,13 +522,17 @@ def test_split_tables_never_change_the_mask(ctx):
         ctx.h2d(d_pos, wl.positions)
         for kernel in (3, 8):
             ctx.set_option("kernel", kernel)
-            for life, piece, maxp, end in ((40.0, 10.0, 8, 0.0), (10.0, 3.0, 16, 0.0), (3.0, 1.0, 4, 0.0), (15.0, 5.0, 8, 40.0)):
-                tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=life, piece_us=piece,
-                                                max_pieces=maxp, end_after_us=end)
-                assert ctx.get_option("split_tiles") == tiles and ctx.get_option("split_pieces") == pieces
-                assert pieces >= 2 * tiles
+            # (life, piece, max pieces, ended after, front tiles: lived longer than / the longest share)
+            for life, piece, maxp, end, front, share in ((40.0, 10.0, 8, 0.0, 0.0, 0.0), (10.0, 3.0, 16, 0.0, 0.0, 0.0), (3.0, 1.0, 4, 0.0, 0.0, 0.0),
+                                                         (30.0, 8.0, 8, 0.0, 6.0, 0.0), (1e9, 1e9, 8, 0.0, 0.0, 0.5), (25.0, 8.0, 8, 20.0, 0.0, 1.0),
+                                                         (15.0, 5.0, 8, 40.0, 0.0, 0.0)):
+                tiles, records = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=life, piece_us=piece,
+                                                 max_pieces=maxp, end_after_us=end, front_life_us=front, front_share=share)
+                split, fronts = ctx.get_option("split_tiles"), ctx.get_option("front_tiles")
+                assert split + fronts == tiles and ctx.get_option("split_pieces") == records and records >= 2 * split + fronts
+                assert (fronts > 100) == (front > 0 or share > 0 or split == 4096), (life, front, share, split, fronts)
                 got = _device_frame(ctx, wl, d_pos, d_mask)
-                assert (got == want).all(), (kernel, life, piece, maxp, tiles, int((got != want).sum()))
+                assert (got == want).all(), (kernel, life, piece, maxp, front, share, tiles, int((got != want).sum()))
             assert tiles > 100                                            # the aggressive plans really split many tiles
             plan = ctx.split_plan()
             assert plan is not None and plan["max_pieces"] == 8 and abs(plan["min_life_us"] - 15.0) < 1e-6

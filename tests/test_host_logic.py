@@ -212,3 +212,32 @@ def test_bench_passes_the_autotuners_launch_options_on_as_text():
     bench.apply_options(r, "")
     assert len(r.calls) == 2
     assert set(bench.TUNED_OPTIONS) == {"packet_share", "row_order"}
+
+
+def test_headline_fraction_is_the_useful_share_and_split_plans_round_trip_as_text():
+    """`roofline.frac` = issue fraction x lane_fill_members (a kernel that does the same work in fewer
+    instructions must not score lower), the raw issue fraction kept beside it; and the split plan of the tuning child reaches
+    the profiler children and the parent as text."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    roof = {"bound": "valu_issue", "frac": 0.62, "achieved": 0.31, "unit": "wave64 VALU instr / clk / SIMD",
+            "valu_issue": {"frac": 0.62, "achieved": 0.31}}
+    out = bench.headline_fraction(dict(roof), 0.79)
+    assert out["frac"] == round(0.62 * 0.79, 4) and out["frac_valu_issue_raw"] == 0.62 and out["lane_fill_members"] == 0.79
+    assert abs(out["achieved"] - 0.31 * 0.79) < 1e-4 and out["unit"].startswith("useful")
+    # fewer instructions at the same time and the same useful work: the raw fraction drops, the useful one does not rise above it
+    leaner = bench.headline_fraction({"bound": "valu_issue", "frac": 0.55, "achieved": 0.275, "valu_issue": {"frac": 0.55, "achieved": 0.275}}, 0.89)
+    assert abs(leaner["frac"] - out["frac"]) < 0.001
+    hbm = {"bound": "hbm", "frac": 0.16, "valu_issue": {"frac": 0.3, "achieved": 0.15}}
+    assert bench.headline_fraction(dict(hbm), 0.8)["frac"] == 0.16                 # another bound: untouched
+    assert bench.headline_fraction(dict(roof), None)["frac"] == 0.62
+    plan = {"min_life_us": 20.25, "end_after_us": 67.5, "piece_us": 10.125, "front_life_us": 0.0, "front_share": 0.3125, "max_pieces": 8,
+            "max_tiles": 8192, "split_tiles": 5, "pieces": 20, "front_tiles": 700}
+    text = bench.splits_arg(plan)
+    back = bench.parse_splits(text)
+    assert back == {"min_life_us": 20.25, "end_after_us": 67.5, "piece_us": 10.125, "front_life_us": 0.0, "front_share": 0.3125,
+                    "max_pieces": 8, "max_tiles": 8192}
+    assert bench.splits_arg(None) == "" and bench.parse_splits("") is None

@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--piece", type=float, default=15.0)
     ap.add_argument("--max-pieces", type=int, default=8)
     ap.add_argument("--options", default="")
+    ap.add_argument("--stripe", default="", help="n:r = the dispatch of stripe r of an n-way interleaved partition (32-row bands) instead of the frame")
+    ap.add_argument("--tiles", type=int, default=0, help="max_tiles of the plan (0 = the library's 4096)")
+    ap.add_argument("--front", type=float, default=0.0, help="front_life_us: tiles that lived longer start first, unsplit")
     args = ap.parse_args()
+    stripes = (32, int(args.stripe.split(":")[0]), int(args.stripe.split(":")[1])) if args.stripe else None
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config, cache=True)
     W, H = wl.W, wl.H
@@ -33,7 +37,10 @@ def main():
         ctx.h2d(d_pos, wl.positions)
 
         def go():
-            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+            if stripes:
+                ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, stripes[0], stripes[1], stripes[2], light=wl.light)
+            else:
+                ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light)
 
         def med(n=60):
             for _ in range(200):
@@ -46,6 +53,9 @@ def main():
 
         plain = med()
         waves = ((W + 7) // 8) * ((H + 7) // 8)
+        if stripes:
+            bands = (H + 31) // 32
+            waves = ((W + 7) // 8) * (((bands - stripes[2] + stripes[1] - 1) // stripes[1]) * 4)
         ctx.set_option("wave_stats", waves)
         go(); go(); ctx.synchronize()
         st, rt = ctx.read_wave_stats(waves), ctx.read_wave_realtime(waves)
@@ -54,10 +64,12 @@ def main():
         life = (rt[:, 1] - rt[:, 0]).astype(np.float64) / 100.0
         start = (rt[:, 0] - t0).astype(np.float64) / 100.0
         end = (rt[:, 1] - t0).astype(np.float64) / 100.0
+        busy = life.sum() / 8192.0
+        print(f"[{args.config}{' stripe ' + args.stripe if stripes else ''}] {waves} waves, sum of wave lives / 8192 slots = {busy:.1f} us")
         print(f"[{args.config}] kernel {args.kernel}: plain frame {plain * 1e3:.1f} us; with wave statistics: last wave starts at {start.max():.1f} us, "
               f"last ends at {end.max():.1f} us; wave life mean {life.mean():.1f} p50 {np.percentile(life, 50):.1f} p99 {np.percentile(life, 99):.1f} max {life.max():.1f} us")
         tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=args.life, piece_us=args.piece,
-                                        max_pieces=args.max_pieces, end_after_us=args.end * plain * 1e3)
+                                        max_pieces=args.max_pieces, end_after_us=args.end * plain * 1e3, stripes=stripes, max_tiles=args.tiles, front_life_us=args.front)
         if not pieces:
             print("no tiles selected")
             return
@@ -65,6 +77,12 @@ def main():
         split = med()
         go(); ctx.synchronize()
         rec, clk = ctx.read_piece_stats(pieces)
+        is_piece = (rec[:, 3] >> 24) > 0                       # (front tiles are walked by the everyday path: no stamps)
+        print(f"records: {int(is_piece.sum())} pieces of {ctx.get_option('split_tiles')} split tiles, {ctx.get_option('front_tiles')} front tiles")
+        rec, clk = rec[is_piece], clk[is_piece]
+        if not len(rec):
+            ctx.free(d_pos); ctx.free(d_mask)
+            return
         p0 = clk[:, 0].min()
         plife = (clk[:, 1] - clk[:, 0]).astype(np.float64) / 100.0
         pend = (clk[:, 1] - p0).astype(np.float64) / 100.0

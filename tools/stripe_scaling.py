@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--band", type=int, default=32)
     ap.add_argument("--kernel", type=int, default=-2, help="kernel id; -1 = library default; -2 = rts_ctx_autotune on the full frame (as bench.py does)")
     ap.add_argument("--options", default="", help="comma list of key=value context options")
+    ap.add_argument("--tune-stripes", action="store_true",
+                    help="every stripe tuned on its own dispatch (rts_ctx_autotune_stripes: kernel, dissolve threshold, split table) -- "
+                         "what rank r of `bench.py --gpus N` does since round 4")
     args = ap.parse_args()
     from raytracedshadows_amd import api, workloads
     wl = workloads.prepare_config(args.config, cache=True)
@@ -38,11 +41,18 @@ def main():
         base = None
         for n in (1, 2, 4, 8):
             worst, times = 0.0, []
+            tuned = []
             for r in range(n):
                 def go():
                     ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, args.band, n, r, light=wl.light)
                 for _ in range(300):
                     go()
+                if args.tune_stripes:
+                    ctx.set_option("packet_share", 4)
+                    kid, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light, stripes=(args.band, n, r))
+                    tuned.append(f"k{kid}/s{ctx.get_option('packet_share')}/{ctx.get_option('split_tiles')}t")
+                    for _ in range(100):
+                        go()
                 ts = []
                 for _ in range(40):
                     ctx.timer_mark(0); go(); ctx.timer_mark(1)
@@ -51,8 +61,8 @@ def main():
             worst = max(times)
             base = base or worst
             print(f"[{args.config}] band {args.band}, {n} stripe(s): per-stripe ms {' '.join(f'{t:.4f}' for t in times)}; slowest {worst:.4f} ms "
-                  f"-> {wl.rays / worst / 1e6:.1f} Grays/s aggregate, predicted efficiency {base / (n * worst) * 100:.0f} % ({ctx.last_kernel_name()})",
-                  flush=True)
+                  f"-> {wl.rays / worst / 1e6:.1f} Grays/s aggregate, predicted efficiency {base / (n * worst) * 100:.0f} % ({ctx.last_kernel_name()})"
+                  + (f" tuned per stripe (kernel/share/split tiles): {' '.join(tuned)}" if tuned else ""), flush=True)
         ctx.free(d_pos)
         ctx.free(d_mask)
 
