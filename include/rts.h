@@ -153,7 +153,8 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
 
 /* Tuning knobs.  Results never depend on any of them (tests/test_gpu_parity.py).  Unknown key or bad value ->
  * RTS_ERR_INVALID_ARG.
- *   "kernel"        -1 = auto (default: packet kernel for >= 256 K pixels, variant 7 below); 0 straight,
+ *   "kernel"        -1 = auto (default: variant 7 below 256 K pixels, the packet kernel 3 from there, the wide packet 8 for
+ *                   one-sample dispatches of >= 4 M pixels when the stream has a private copy); 0 straight,
  *                   1 while-while, 2 postpone, 3 packet (8x8 px / wave), 4 packet2 (16x8), 5 packet4 (16x16),
  *                   6 packet + successor prefetch, 7 lane-per-ray with work sharing, 8 WIDE packet (a private copy of the
  *                   stream with four boxes per node: one dependent fetch decides two levels of the reference's walk; a

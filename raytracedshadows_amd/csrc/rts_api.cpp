@@ -398,7 +398,13 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows;
     }
     const uint64_t pixels = (uint64_t)W * rows;
-    if (variant == rts::V_AUTO) variant = pixels >= (1u << 18) ? rts::V_PACKET : rts::V_SHARE;
+    // Big one-sample dispatches of a stream with a private copy take the WIDE packet (a static rule from what rts_ctx_autotune
+    // picks on the 4K frames: city 0.153 against 0.164 ms, courtyard 0.562 against 0.630; at 1080p and for soft shadows the
+    // stackless packet is ahead or level -- profiles/r04/tuning_robustness.log): a caller that never tunes gets the kernel the
+    // tuner would have picked there, not its launch options.
+    if (variant == rts::V_AUTO)
+        variant = pixels < (1u << 18) ? rts::V_SHARE
+                : (c->wideCount && (!light || light->nsamples <= 1) && pixels >= (1u << 22) && c->blockWaves == 1) ? rts::V_WIDE : rts::V_PACKET;
     if ((variant == rts::V_WIDE || variant == rts::V_WIDE_C) && !p.wide) variant = rts::V_PACKET;     // no private copy for this stream (see finishInstall)
     uint32_t bw, bh;
     rts::tileShape(variant, c->blockWaves, &bw, &bh);

@@ -1451,7 +1451,11 @@ void shadowMaskPacketKernel(TraceParams p) {
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k)
+#ifdef RTS_EXPERIMENT_NO_MASK_STORE      // (experiment build only, tools/mask_store_ab.sh: what the byte stores cost -- nothing is ever stored)
+            if (live[k] && lit[k] > 200u) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);
+#else
             if (live[k]) __builtin_nontemporal_store((uint8_t)lit[k], &p.mask[pix[k]]);   // comp:150
+#endif
     }
     if (probed) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;

@@ -107,6 +107,13 @@ def test_config2_city_4k_full_size(ctx, city4k):
     want = _check_workload(ctx, city4k, swizzles=(0, 1))
     assert (want == city4k.want).all()
     assert 0.2 < want.mean() < 0.8                                                # a real mix of lit / occluded
+    # the library default on a one-sample frame of this size is the wide packet (a static rule: no tuning call needed);
+    # the same frame with 16 samples and a 1080p frame keep the stackless packet
+    ctx.set_option("kernel", -1)
+    got = ctx.trace_shadow_mask(city4k.constants, city4k.positions, city4k.W, city4k.H, light=city4k.light)
+    assert ctx.last_kernel_name() == "shadowMaskPacketKernel<1,wide>" and (got == want).all()
+    ctx.trace_shadow_mask(city4k.constants, city4k.positions, city4k.W, city4k.H, light=city4k.light, row_begin=0, row_end=1080)
+    assert ctx.last_kernel_name() == "shadowMaskPacketKernel<1>"
 
 
 def test_reference_directional_light_city_4k_full_size(ctx, city4k):
