@@ -320,6 +320,11 @@ int rts_ctx_get_split_plan(rts_ctx* ctx, rts_split_plan* out);
  * lane-per-ray phase, end of the walk}, {wide nodes entered | stack entries at the dissolve << 32}, lanes found occluded.
  * Either pointer may be NULL. */
 int rts_ctx_read_piece_stats(rts_ctx* ctx, uint32_t* records, uint64_t* clocks, size_t pieces);
+/* Self-test behind one of the kernels' shortcuts: 1.0f / x (comp:44, comp:77) is computed as v_rcp_f32 + one Newton step in
+ * fma arithmetic when 2^-100 <= |x| <= 2^100 in a whole wave.  That this is the correctly rounded quotient is checked HERE for
+ * every bit pattern of the range on the context's device: out[0] = patterns checked (3 355 443 200), out[1] = patterns whose
+ * result differs from the IEEE division -- 0 on gfx950 --, out[2] = one such pattern.  A fraction of a second. */
+int rts_selftest_reciprocal(rts_ctx* ctx, uint64_t out[3]);
 /* Same launch, 4 x u64 per wave: s_memrealtime (the constant 100 MHz counter) at the wave's start and end, shader clocks
  * from the wave's start to its first ray being ready (G-buffer texel in, ray set up), XCC id.  With the start/end shader
  * clocks above: clock held under load = sum(end - start clocks) / sum(end - start realtime) * 100 MHz. */

@@ -164,6 +164,7 @@ _sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants),
 _sig("rts_ctx_plan_splits_stripes", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32,
      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rts_ctx_clear_splits", C.c_int, C.c_void_p)
+_sig("rts_selftest_reciprocal", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_ctx_get_split_plan", C.c_int, C.c_void_p, C.POINTER(SplitPlan))
 _sig("rts_ctx_autotune_stripes", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
      C.c_uint32, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float))
@@ -492,6 +493,12 @@ class ShadowContext:
         clk = np.zeros((pieces, 8), np.uint64) if clocks else None
         _check(_lib.rts_ctx_read_piece_stats(self._h, _ptr(rec), _ptr(clk) if clocks else None, pieces), "rts_ctx_read_piece_stats")
         return rec, clk
+
+    def selftest_reciprocal(self):
+        """(patterns checked, patterns that differ from the IEEE division, an example): rts_selftest_reciprocal."""
+        out = np.zeros(3, np.uint64)
+        _check(_lib.rts_selftest_reciprocal(self._h, _ptr(out)), "rts_selftest_reciprocal")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def clear_splits(self):
         _check(_lib.rts_ctx_clear_splits(self._h), "rts_ctx_clear_splits")

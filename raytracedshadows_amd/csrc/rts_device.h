@@ -85,6 +85,7 @@ const char* kernelName(int variant, bool mask);
 void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* blockH);   // pixels covered by one block
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad = 0);
 hipError_t launchTraceRays(int variant, const TraceParams& p, hipStream_t stream);
+hipError_t launchReciprocalSelfTest(unsigned long long* d_counts, hipStream_t stream);      // 3 counters, zeroed by the caller
 // planning: from the visit logs of `tiles` one-piece walks (p.pieceLog layout) to the piece table: tile t gets cuts[t].pieces
 // records starting at record firstPiece[t], its index ranges cut at the quantiles of its log
 hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const SplitCut* d_cuts, const uint32_t* d_firstPiece,

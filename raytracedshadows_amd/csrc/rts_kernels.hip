@@ -57,10 +57,27 @@ __device__ __forceinline__ bool boxHit(const Ray& r, float lox, float loy, float
     }
 }
 
+// 1.0f / x, correctly rounded, in three instructions where that is proven: for 2^-100 <= |x| <= 2^100, v_rcp_f32 followed by one
+// Newton step in fma arithmetic IS the IEEE quotient on gfx950 -- checked for every one of the 2^32 bit patterns against the
+// division (rts_selftest_reciprocal below, run by the -m gpu suite; Markstein's theorem covers all but the all-ones mantissas,
+// the exhaustive run covers those too; the range keeps every intermediate normal).  Callers decide per WAVE (one ballot) and
+// keep the general division -- eleven instructions -- for waves with a value outside the range (0, denormal, huge, Inf, NaN).
+__device__ __forceinline__ bool rcpInRange(float x) {
+    const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;               // biased exponent: 27 .. 227 <=> 2^-100 <= |x| < 2^101
+    return e - 27u <= 199u;                                               // ... cut at 2^100 exclusive of the last binade: 27 .. 226
+}
+__device__ __forceinline__ float rcpFast(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
 // comp:41-59
 __device__ __forceinline__ bool triHit(const Ray& r, F3 v0, F3 e0, F3 e1) {
     F3 s1 = cross3(r.d, e1);
-    float invd = 1.0f / dot3(s1, e0);
+    const float det = dot3(s1, e0);
+    float invd;                                                          // = 1.0f / det (comp:44), bit for bit
+    if (__builtin_amdgcn_ballot_w64(!rcpInRange(det)) == 0) invd = rcpFast(det); else invd = 1.0f / det;
     F3 dd = sub3(r.o, v0);
     float b1 = dot3(dd, s1) * invd;
     F3 s2 = cross3(dd, e0);
@@ -112,12 +129,18 @@ __device__ __forceinline__ Ray makeShadowRay(const TraceParams& p, F3 rel, uint3
         r.o = origin; r.tmax = 1e9f; r.d = L;
     } else {
         F3 d0 = sub3(L, origin);
-        float inv = 1.0f / __builtin_sqrtf(dot3(d0, d0));
+        const float len = __builtin_sqrtf(dot3(d0, d0));
+        // (lanes without a pixel carry texel 0 or zeros: they share the decision, which is only about speed)
+        float inv;
+        if (__builtin_amdgcn_ballot_w64(!rcpInRange(len)) == 0) inv = rcpFast(len); else inv = 1.0f / len;
         origin.x = origin.x + (d0.x * inv) * bias; origin.y = origin.y + (d0.y * inv) * bias;
         origin.z = origin.z + (d0.z * inv) * bias;
         r.o = origin; r.tmax = 1.0f; r.d = sub3(L, origin);
     }
-    r.inv = F3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };   // comp:77
+    if (__builtin_amdgcn_ballot_w64(!(rcpInRange(r.d.x) && rcpInRange(r.d.y) && rcpInRange(r.d.z))) == 0)
+        r.inv = F3{ rcpFast(r.d.x), rcpFast(r.d.y), rcpFast(r.d.z) };
+    else
+        r.inv = F3{ 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };   // comp:77
     return r;
 }
 
@@ -1704,6 +1727,29 @@ hipError_t launchSplitQuantiles(const uint32_t* d_log, uint32_t logCap, const Sp
     if (tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(splitQuantilesKernel, dim3(tiles), dim3(256), 0, stream, d_log, logCap, d_cuts, d_firstPiece, tiles, d_pieces,
                        (const uint32_t*)d_wide);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test of rcpFast (the exactness argument of the fast reciprocal is this run): every bit pattern x with rcpInRange(x)
+// must give the bits of 1.0f / x; counts[0] = patterns in range, counts[1] = of those, patterns that differ, counts[2] = an
+// example.  2^32 divisions: a fraction of a second.
+// ------------------------------------------------------------------------------------------------
+__global__ void reciprocalSelfTestKernel(unsigned long long* counts) {
+    unsigned long long in = 0, bad = 0;
+    uint32_t example = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        if (!rcpInRange(x)) continue;
+        ++in;
+        if (__float_as_uint(rcpFast(x)) != __float_as_uint(1.0f / x)) { ++bad; example = (uint32_t)i; }
+    }
+    atomicAdd(&counts[0], in);
+    if (bad) { atomicAdd(&counts[1], bad); counts[2] = example; }
+}
+
+hipError_t launchReciprocalSelfTest(unsigned long long* d_counts, hipStream_t stream) {
+    hipLaunchKernelGGL(reciprocalSelfTestKernel, dim3(256 * 16), dim3(256), 0, stream, d_counts);
     return hipGetLastError();
 }
 

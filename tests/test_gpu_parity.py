@@ -708,6 +708,15 @@ def test_split_tables_full_size(ctx, name):
         ctx.free(d_mask)
 
 
+def test_fast_reciprocal_is_the_ieee_quotient_for_every_input_it_is_used_on(ctx):
+    """The kernels compute 1.0f / x (comp:44 in the triangle test, comp:77 for 1/d) as v_rcp_f32 + one Newton step when a whole
+    wave's values lie in [2^-100, 2^100), and by the general division otherwise.  The shortcut's exactness argument is this
+    run: all 3 355 443 200 bit patterns of the range, on this device, against the division."""
+    checked, differ, example = ctx.selftest_reciprocal()
+    assert checked == 200 * (1 << 23) * 2
+    assert differ == 0, f"{differ} inputs differ, e.g. 0x{example:08x}"
+
+
 def test_non_finite_bvh_takes_the_exact_path(ctx):
     """A packed buffer from another producer may carry Inf boxes: the fast slab test must not be used."""
     sc = scenes.terrain(9)

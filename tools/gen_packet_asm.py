@@ -275,7 +275,19 @@ def loop_leaf(form):
           "v_mul_f32 %[t2], s45, %[dx0]", "v_mul_f32 %[t3], s44, %[dy0]", "v_sub_f32 %[t2], %[t2], %[t3]",   # s1.z = d.x*e1.y - e1.x*d.y
           "v_mul_f32 %[t3], s40, %[t0]", "v_mul_f32 %[t4], s41, %[t1]", "v_add_f32 %[t3], %[t3], %[t4]",
           "v_mul_f32 %[t4], s42, %[t2]", "v_add_f32 %[t3], %[t3], %[t4]",                                     # det = dot(s1, e0)
-          # invd = 1.0f / det, correctly rounded (the sequence hipcc emits)
+          # invd = 1.0f / det, correctly rounded.  Where every lane's det has a biased exponent in 27..226 (2^-100 <= |det| <
+          # 2^100): v_rcp_f32 + one Newton step, which IS the IEEE quotient there (every bit pattern checked on the device:
+          # rts_selftest_reciprocal, rts_kernels.hip: rcpFast); otherwise the general division (the sequence hipcc emits).
+          "v_bfe_u32 %[t5], %[t3], 23, 8",
+          "v_subrev_u32 %[t5], 27, %[t5]",
+          "v_cmp_lt_u32 vcc, 0xc7, %[t5]",                # lanes out of the range (unsigned: also exponents below 27)
+          "s_cbranch_vccnz 11f",
+          "v_rcp_f32 %[t4], %[t3]",
+          "s_nop 0",                                     # (gfx940+: a VALU op that reads a transcendental's result needs one wait state; the assembler adds none)
+          "v_fma_f32 %[t5], -%[t3], %[t4], 1.0",
+          "v_fma_f32 %[t4], %[t5], %[t4], %[t4]",
+          "s_branch 12f",
+          "11:",
           "v_div_scale_f32 %[t5], s[60:61], %[t3], %[t3], 1.0",
           "v_rcp_f32 %[t7], %[t5]",
           "v_div_scale_f32 %[t6], vcc, 1.0, %[t3], 1.0",
@@ -287,6 +299,7 @@ def loop_leaf(form):
           "v_fma_f32 %[t5], -%[t5], %[t8], %[t6]",
           "v_div_fmas_f32 %[t5], %[t5], %[t7], %[t8]",
           "v_div_fixup_f32 %[t4], %[t5], %[t3], 1.0",                                                          # invd
+          "12:",
           "s_waitcnt lgkmcnt(0)",
           "v_subrev_f32 %[t5], s56, %[ox0]", "v_subrev_f32 %[t6], s57, %[oy0]", "v_subrev_f32 %[t7], s58, %[oz0]",   # dd = o - v0
           "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",

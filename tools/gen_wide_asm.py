@@ -146,7 +146,7 @@ def exact_box(k, octant, dst):
     return L
 
 
-def triangle(dst):
+def triangle(dst, tag=0):
     """Moeller-Trumbore exactly as comp:41-59 spells it (separate mul/sub/add, dots left to right, correctly rounded
     1/det: the sequence hipcc emits for 1.0f / x); v0 = T0-2, e0 = T3-5, e1 = T6-8.  dst = lanes of EXEC that are REJECTED.
     Ten temporaries: s2 takes the registers of s1 once b1 exists, b2 / t / b1+b2 those of dd once s2 exists (the number of
@@ -158,6 +158,18 @@ def triangle(dst):
         f"v_mul_f32 %[t2], {e1[1]}, %[dx]", f"v_mul_f32 %[t3], {e1[0]}, %[dy]", "v_sub_f32 %[t2], %[t2], %[t3]",   # s1.z = d.x*e1.y - e1.x*d.y
         f"v_mul_f32 %[t3], {e0[0]}, %[t0]", f"v_mul_f32 %[t4], {e0[1]}, %[t1]", "v_add_f32 %[t3], %[t3], %[t4]",
         f"v_mul_f32 %[t4], {e0[2]}, %[t2]", "v_add_f32 %[t3], %[t3], %[t4]",                                       # det = dot(s1, e0)
+        # 1/det: rcp + one Newton step where every lane's |det| is in [2^-100, 2^100) (the IEEE quotient there: every bit pattern
+        # checked on the device, rts_selftest_reciprocal); otherwise the general division
+        "v_bfe_u32 %[t5], %[t3], 23, 8",
+        "v_subrev_u32 %[t5], 27, %[t5]",
+        "v_cmp_lt_u32 vcc, 0xc7, %[t5]",
+        f"s_cbranch_vccnz 17{tag}f",
+        "v_rcp_f32 %[t4], %[t3]",
+        "s_nop 0",                                       # (gfx940+: a VALU op that reads a transcendental's result needs one wait state; the assembler adds none)
+        "v_fma_f32 %[t5], -%[t3], %[t4], 1.0",
+        "v_fma_f32 %[t4], %[t5], %[t4], %[t4]",
+        f"s_branch 18{tag}f",
+        f"17{tag}:",
         f"v_div_scale_f32 %[t5], {R}, %[t3], %[t3], 1.0",
         "v_rcp_f32 %[t7], %[t5]",
         "v_div_scale_f32 %[t6], vcc, 1.0, %[t3], 1.0",
@@ -169,6 +181,7 @@ def triangle(dst):
         "v_fma_f32 %[t5], -%[t5], %[t8], %[t6]",
         "v_div_fmas_f32 %[t5], %[t5], %[t7], %[t8]",
         "v_div_fixup_f32 %[t4], %[t5], %[t3], 1.0",                                                                # invd
+        f"18{tag}:",
         f"v_subrev_f32 %[t5], {v0[0]}, %[ox]", f"v_subrev_f32 %[t6], {v0[1]}, %[oy]", f"v_subrev_f32 %[t7], {v0[2]}, %[oz]",   # dd = o - v0
         "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
         "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]",       # b1 = dot(dd, s1) * invd
@@ -288,7 +301,7 @@ def loop(octant):
               f"s_load_dwordx8 s[{BASE + 28}:{BASE + 35}], %[tb], {REF}",
               f"s_load_dword {T(8)}, %[tb], {REF} offset:32",
               "s_waitcnt lgkmcnt(0)"]
-        L += triangle(R)
+        L += triangle(R, k)
         L += [f"s_andn2_b64 exec, exec, {R}",                   # lanes whose ray hits the triangle
               f"s_cbranch_scc0 6{k}f"]
         L += exact_box(k, octant, R)                             # ... count iff the ray reaches the leaf: exact test of its parent's box
@@ -406,7 +419,7 @@ def loop_range():
               f"s_load_dwordx8 s[{BASE + 28}:{BASE + 35}], %[tb], {REF}",
               f"s_load_dword {T(8)}, %[tb], {REF} offset:32",
               "s_waitcnt lgkmcnt(0)"]
-        L += triangle(R)
+        L += triangle(R, k)
         L += [f"s_andn2_b64 exec, exec, {R}",
               f"s_cbranch_scc0 6{k}f"]
         L += exact_box(k, octant, R)
