@@ -29,12 +29,22 @@ find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/city4k_kernel_stats.c
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_courtyard -- python3 $REPO/bench.py --config courtyard_4k --kernel 8 --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_courtyard.json 2> $OUT/trace_bench_courtyard.err); echo "trace courtyard rc=$?"
 find $OUT/trace_courtyard -name "*kernel_stats.csv" -exec cp {} $OUT/courtyard4k_kernel_stats.csv \;
 rm -rf $OUT/trace $OUT/trace_courtyard
-for K in 3 8; do for CFG in city_4k courtyard_4k atrium_1080p; do
+for a in "city_4k 8" "courtyard_4k 8" "atrium_1080p 3"; do set -- $a; CFG=$1; K=$2
   timeout -k 10 300 python tools/floor_analysis.py --config $CFG --kernel $K 2>&1 | grep -v "one-triangle" | grep -A6 "BVH\]" > $OUT/floor_analysis_${CFG}_kernel$K.log
   timeout -k 10 300 python tools/long_waves.py --config $CFG --kernel $K 2>&1 | tail -2 > $OUT/long_waves_${CFG}_kernel$K.log
-done; done
-for a in "city_4k 3" "city_4k 8" "courtyard_4k 3" "courtyard_4k 8" "city_4k_soft16 3"; do set -- $a
+done
+for a in "city_4k 8" "courtyard_4k 8" "city_4k_soft16 3"; do set -- $a
   timeout -k 10 300 python tools/stripe_scaling.py --config $1 --kernel $2 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_$1_kernel$2.log; tail -1 $OUT/stripe_scaling_$1_kernel$2.log | cut -c1-60; done
-timeout -k 10 300 python tools/stripe_scaling.py --config city_4k_soft16 --kernel 3 --options soft_split=0 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_city_4k_soft16_kernel3_no_split.log
-timeout -k 10 200 tools/microbench/node_fetch > $OUT/node_fetch_microbench.log 2>&1; cat $OUT/node_fetch_microbench.log
+# ... and what rank r of `bench.py --gpus N` executes since round 4: every stripe tuned on its own dispatch (kernel, share, split table)
+for CFG in city_4k courtyard_4k; do
+  timeout -k 10 400 python tools/stripe_scaling.py --config $CFG --tune-stripes 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_${CFG}_tuned_per_stripe.log; tail -1 $OUT/stripe_scaling_${CFG}_tuned_per_stripe.log | cut -c1-120; done
+# split tables: the pieces' lives against the tiles' own waves; the tuner's choice on a moved camera / light; kernel stats of the table launch
+timeout -k 10 200 python tools/piece_stats.py --config atrium_1080p --kernel 3 --life 33 --end 0.5 --piece 13 --front 0 2>&1 | grep -v "^   " > $OUT/piece_stats_atrium_1080p.log
+timeout -k 10 900 python tools/tuning_robustness.py atrium_1080p city_4k courtyard_4k > $OUT/tuning_robustness.log 2>&1; grep -c reuse $OUT/tuning_robustness.log
+ASPLITS=$(python -c "import json,sys; sys.path.insert(0,'$REPO'); import bench; t=json.load(open('$OUT/bench_atrium_1080p.json'))['config'].get('split_table'); print(bench.splits_arg(t['plan']) if t else '')")
+AOPT=$(python -c "import json; print(json.load(open('$OUT/bench_atrium_1080p.json'))['config'].get('launch_options', ''))")
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_atrium -- python3 $REPO/bench.py --config atrium_1080p --kernel 3 --options "$AOPT" --splits "$ASPLITS" --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_atrium.json 2> $OUT/trace_bench_atrium.err); echo "trace atrium rc=$?"
+find $OUT/trace_atrium -name "*kernel_stats.csv" -exec cp {} $OUT/atrium1080p_kernel_stats.csv \;
+rm -rf $OUT/trace_atrium
+timeout -k 10 100 python tools/phase_shares.py courtyard_4k 8 2>&1 | grep -A4 "^\[" > $OUT/phase_shares.log; timeout -k 10 100 python tools/phase_shares.py city_4k 8 2>&1 | grep -A4 "^\[" >> $OUT/phase_shares.log
 timeout -k 10 300 python tools/host_path_timing.py > $OUT/host_path_timing.log 2>&1; tail -2 $OUT/host_path_timing.log
