@@ -15,8 +15,9 @@ once per GPU, disjoint output), torch.distributed (gloo) is only the barrier / m
 
 Timing: a time-based pre-warm (back-to-back launches until the clocks have ramped), W untimed warm-up steps, then
 exactly K steps between barrier + synchronize on both sides; `value` = rays / (max over ranks of that wall time).
-Every step is also bracketed by HIP events on the launch stream: `ms_per_frame_gpu_median` is the figure the
-reference's on-screen counter shows (RayTracedShadows.cpp:263-265).
+HIP events on the launch stream bracket the K launches (`ms_per_frame_gpu_mean`, the roofline's launch duration); right
+after the timed region the same launch runs again with an event pair per frame: `ms_per_frame_gpu_median` is the figure
+the reference's on-screen counter shows (RayTracedShadows.cpp:263-265).
 
 Rank 0 prints ONE JSON line.  Before timing, every rank checks its GPU mask against the CPU oracle
 on every pixel it owns (the correctness gate of SURVEY.md 8d); a mismatch aborts.
@@ -421,21 +422,31 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
             step()
         ctx.synchronize()
         prewarm_launches += 50
+    ctx.timer_mark(0); ctx.timer_mark(1)                         # (the two events of the timed region exist before it starts)
     for _ in range(warmup):
         step()
     if barrier:
         barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
+    ctx.timer_mark(0)                                            # HIP events on the launch stream around the K launches ...
     for i in range(steps):
-        ctx.timer_mark(i)
         step()
-    ctx.timer_mark(steps)
+    ctx.timer_mark(1)
     ctx.synchronize()
     wall = time.perf_counter() - t0
     if barrier:
         barrier()
-    per_launch = np.array([ctx.timer_between_ms(i, i + 1) for i in range(steps)])   # HIP events, launch stream
+    events_ms = ctx.timer_between_ms(0, 1)                       # ... their span / K = the average launch duration of the timed region
+    # per-launch figures (the reference's on-screen counter brackets every frame, cpp:572-594) from a run of the same launch right
+    # after the timed region: an event between two launches costs the queue 1-2 us, so the timed region carries none inside
+    n_single = max(10, min(steps, 100))
+    for i in range(n_single):
+        ctx.timer_mark(2 + i)
+        step()
+    ctx.timer_mark(2 + n_single)
+    ctx.synchronize()
+    per_launch = np.array([ctx.timer_between_ms(2 + i, 3 + i) for i in range(n_single)])
     clock = None
     if probe_rows:
         # the shader clock from a probed run of the same launch RIGHT AFTER the timed region (the probe -- one wave per tile row
@@ -448,7 +459,7 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
             clock = ctx.clock_probe_mhz(probe_rows)
         finally:
             ctx.set_option("clock_probe", 0)
-    return {"wall": wall, "kernel_ms": float(per_launch.sum()), "median_ms": float(np.median(per_launch)),
+    return {"wall": wall, "kernel_ms": float(events_ms), "median_ms": float(np.median(per_launch)),
             "prewarm_launches": prewarm_launches, "clock_mhz": clock}
 
 

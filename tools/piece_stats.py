@@ -97,8 +97,7 @@ def main():
         lane = f(clk[diss, 5] - clk[diss, 4])
         tail = f(clk[:, 1] - clk[:, 5])
         nodes, entries = (clk[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.float64), (clk[:, 6] >> np.uint64(32)).astype(np.float64)
-        print(f"where a piece's time goes (means, us): ray set-up {setup.mean():.2f}; packet phase {packet.mean():.2f} over {nodes.mean():.1f} wide nodes "
-              f"({packet.sum() / max(1.0, nodes.sum()):.3f} us per node); {diss.mean() * 100:.0f} % dissolve: hand-over {handover.mean() if diss.any() else 0:.2f} "
+        print(f"where a piece's time goes (means, us): ray set-up {setup.mean():.2f}; packet phase {packet.mean():.2f} over {nodes.mean() / 4.0:.1f} calls of the loop (<= 4 pops each); {diss.mean() * 100:.0f} % dissolve: hand-over {handover.mean() if diss.any() else 0:.2f} "
               f"({entries[diss].mean() if diss.any() else 0:.1f} stack entries), lane phase {lane.mean() if diss.any() else 0:.2f}; closing atomics {tail.mean():.2f}")
         # per tile: the tile's own wave against its pieces
         key = rec[:, 0]
