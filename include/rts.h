@@ -254,9 +254,9 @@ int rts_ctx_read_clock_probe(rts_ctx* ctx, uint64_t* out, size_t rows);
 /* Picks the kernel for this frame by timing the candidates on it (lane-per-ray with work sharing for small frames, the
  * packet kernel, the wide packet kernel) -- what a renderer does once per scene and resolution; then, for a packet kernel,
  * the dissolve threshold ("packet_share" 4 or 6) and the order in which the tile rows are started ("row_order" 0 or 1), each
- * kept only if it gains 1.5 %; then a split table (rts_ctx_plan_splits below) for the tiles that lived longer than 15 % / 10 %
- * of the frame and ended in its second half / last quarter, kept on the same condition (any table installed before is
- * dropped).  Leaves the options "kernel", "packet_share" and "row_order" set to the winners and the winning table installed
+ * kept only if it gains 1.5 %; then seven split tables (rts_ctx_plan_splits below) planned from one set of wave statistics -- the
+ * tiles that lived longer than a quarter of the frame split or not, the longest 3 % / third / all of the tiles started first --,
+ * the fastest kept on the same condition (any table installed before is dropped).  Leaves the options "kernel", "packet_share" and "row_order" set to the winners and the winning table installed
  * (*chosen = the kernel, median of five launches in *ms; both nullable).  Device pointers, default stream, synchronous.
  * Results never depend on any of it. */
 int rts_ctx_autotune(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
@@ -296,7 +296,9 @@ typedef struct rts_split_plan {
                                     by their own wave, unchanged, but dispatched at the head of the grid (after the pieces, longest
                                     first): what is long starts early, and the dispatch ends with short waves */
     float    front_share;        /* 0..1: ... or, given as a share: the longest front_share of all tiles of the dispatch start first (the
-                                    larger of the two thresholds counts when both are given; a third is what rts_ctx_autotune tries) */
+                                    larger of the two thresholds counts when both are given).  1 = every tile: the WHOLE dispatch runs
+                                    in table order -- half-octaves of measured life, longest first, image order inside one -- and no
+                                    tile rows are launched at all.  rts_ctx_autotune tries 0.03, 1/3 and 1 */
     uint32_t max_pieces;         /* 2..64 */
     uint32_t max_tiles;          /* 0 = 4096 */
     const uint64_t* prev_stats;  /* all three NULL / 0: measure now */

@@ -5,8 +5,10 @@
 #include "rts_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -56,6 +58,7 @@ struct rts_ctx {
         uint32_t* d_skipMap = nullptr;       // one bit per tile of the dispatch
         uint32_t* d_pieces = nullptr;        // 8 dwords per piece
         uint32_t nPieces = 0, pieceRows = 0, nTiles = 0, nFront = 0;      // records (pieces + front tiles), split tiles, front tiles
+        bool allTiles = false;
         rts_split_plan plan{};               // what the table was planned with (rts_ctx_get_split_plan)
         // {occluded lanes, pieces done} per split tile: one buffer per stream that traces with the table, so that frames in
         // flight on different streams never meet in it (frames on one stream follow each other)
@@ -461,6 +464,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         if (uint64_t* st = splitState(c, stream)) {
             p.skipMap = sp.d_skipMap; p.pieces = sp.d_pieces; p.nPieces = sp.nPieces; p.pieceRows = sp.pieceRows;
             p.tileState = st;
+            p.allInTable = sp.allTiles ? 1u : 0u;
             if (c->d_pieceClock && c->pieceClockCount >= sp.nPieces) p.pieceClock = c->d_pieceClock;
         }
     }
@@ -712,6 +716,39 @@ int rts_ctx_read_clock_probe(rts_ctx* c, uint64_t* out, size_t rows) {
     return RTS_OK;
 }
 
+// Wave statistics of ONE dispatch (what rts_ctx_read_wave_stats / _realtime return): two launches of the diagnostic
+// instantiation without a table, the second one read back.  Used by the planner and, once per tuning call, by the tuner.
+static int measureDispatch(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                           uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                           std::vector<uint64_t>& stats, std::vector<uint64_t>& rt) {
+    int status = RTS_OK;
+    uint64_t* keep = c->d_waveStats; const size_t keepBytes = c->waveStatsBytes;
+    c->d_waveStats = nullptr; c->waveStatsBytes = 0;
+    uint32_t rows = row_end - row_begin;
+    if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
+    const size_t waves = (size_t)((W + 7) / 8) * ((rows + 7) / 8);
+    hipError_t e = hipMalloc((void**)&c->d_waveStats, waves * 64);
+    if (e == hipSuccess) e = hipMemset(c->d_waveStats, 0, waves * 64);
+    if (e == hipSuccess) {
+        c->waveStatsBytes = waves * 32;
+        const int use = c->useSplits; c->useSplits = 0;
+        for (int i = 0; i < 2 && status == RTS_OK; ++i)                   // (the second launch is the one that counts: warm caches)
+            status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+        c->useSplits = use;
+        if (status == RTS_OK) e = hipDeviceSynchronize();
+        if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = RTS_ERR_INVALID_ARG;   // not an 8x8-tile kernel
+        if (status == RTS_OK && e == hipSuccess) {
+            stats.resize(waves * 4); rt.resize(waves * 4);
+            e = hipMemcpy(stats.data(), c->d_waveStats, waves * 32, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(rt.data(), c->d_waveStats + waves * 4, waves * 32, hipMemcpyDeviceToHost);
+        }
+    }
+    if (c->d_waveStats) (void)hipFree(c->d_waveStats);
+    c->d_waveStats = keep; c->waveStatsBytes = keepBytes;
+    if (status != RTS_OK) return status;
+    return hipStatus(e);
+}
+
 // Plans the split table for ONE dispatch geometry (see include/rts.h).  Synchronous, default stream.
 static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
                           uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
@@ -737,31 +774,9 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             stats.assign(plan->prev_stats, plan->prev_stats + waves * 4);
             rt.assign(plan->prev_realtime, plan->prev_realtime + waves * 4);
         } else {                                                                 // one launch of this dispatch with wave statistics
-            uint64_t* keep = c->d_waveStats; const size_t keepBytes = c->waveStatsBytes;
-            c->d_waveStats = nullptr; c->waveStatsBytes = 0;
-            uint32_t rows = row_end - row_begin;
-            if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
-            waves = (size_t)((W + 7) / 8) * ((rows + 7) / 8);
-            hipError_t e = hipMalloc((void**)&c->d_waveStats, waves * 64);
-            if (e == hipSuccess) e = hipMemset(c->d_waveStats, 0, waves * 64);
-            if (e == hipSuccess) {
-                c->waveStatsBytes = waves * 32;
-                const int use = c->useSplits; c->useSplits = 0;
-                for (int i = 0; i < 2 && status == RTS_OK; ++i)                   // (the second launch is the one that counts: warm caches)
-                    status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
-                c->useSplits = use;
-                if (status == RTS_OK) e = hipDeviceSynchronize();
-                if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = RTS_ERR_INVALID_ARG;   // not an 8x8-tile kernel
-                if (status == RTS_OK && e == hipSuccess) {
-                    stats.resize(waves * 4); rt.resize(waves * 4);
-                    e = hipMemcpy(stats.data(), c->d_waveStats, waves * 32, hipMemcpyDeviceToHost);
-                    if (e == hipSuccess) e = hipMemcpy(rt.data(), c->d_waveStats + waves * 4, waves * 32, hipMemcpyDeviceToHost);
-                }
-            }
-            if (c->d_waveStats) (void)hipFree(c->d_waveStats);
-            c->d_waveStats = keep; c->waveStatsBytes = keepBytes;
+            status = measureDispatch(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, stats, rt);
             if (status != RTS_OK) return status;
-            if (e != hipSuccess) return hipStatus(e);
+            waves = stats.size() / 4;
         }
         // the tiles whose wave lived longer than min_life_us, longest first
         struct Sel { float us; uint32_t tile; };
@@ -771,7 +786,8 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         uint64_t began = ~0ull;                                                 // the dispatch's first wave
         for (size_t i = 0; i < waves; ++i) if (rt[i * 4 + 1] > rt[i * 4] && rt[i * 4] < began) began = rt[i * 4];
         float frontLife = plan->front_life_us;
-        if (plan->front_share > 0.f) {                                           // the life the longest front_share of the tiles exceed
+        if (plan->front_share >= 1.f) frontLife = 1e-6f;                          // (every tile: the whole dispatch in table order)
+        else if (plan->front_share > 0.f) {                                      // the life the longest front_share of the tiles exceed
             std::vector<float> lives;
             lives.reserve(waves);
             for (size_t i = 0; i < waves; ++i) if (rt[i * 4 + 1] > rt[i * 4]) lives.push_back((float)(rt[i * 4 + 1] - rt[i * 4]) * 0.01f);
@@ -795,7 +811,15 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         if (sel.empty() && front.empty()) return RTS_OK;
         const auto longer = [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); };
         std::sort(sel.begin(), sel.end(), longer);
-        std::sort(front.begin(), front.end(), longer);
+        // front tiles: longest first in half-octaves of life, image order inside one (neighbouring tiles walk the same part of
+        // the tree: started together they share the scalar cache and the L2 as in the plain launch)
+        const auto band = [](float us) { return (int)std::floor(std::log2(us < 0.25f ? 0.25f : us) * 2.f); };
+        std::sort(front.begin(), front.end(), [&](const Sel& a, const Sel& b) {
+            const int ba = band(a.us), bb = band(b.us);
+            if (ba != bb) return ba > bb;
+            const uint32_t ka = ((a.tile >> 16) << 16) | (a.tile & 0xFFFFu), kb = ((b.tile >> 16) << 16) | (b.tile & 0xFFFFu);
+            return ka < kb;
+        });
         if (sel.size() > maxTiles) { front.insert(front.begin(), sel.begin() + maxTiles, sel.end()); sel.resize(maxTiles); }   // (what is not split starts first at least)
         if (front.size() > 262144) front.resize(262144);
         const uint32_t T = (uint32_t)sel.size(), F = (uint32_t)front.size();
@@ -867,6 +891,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         t.blocksX = blocksX; t.blocksY = keyBlocksY;
         t.d_skipMap = (uint32_t*)d_map; t.d_pieces = (uint32_t*)d_pieces;
         t.nPieces = nPieces + F; t.pieceRows = (nPieces + F + blocksX - 1) / blocksX; t.nTiles = T; t.nFront = F;
+        t.allTiles = (size_t)T + F == waves && waves == (size_t)blocksX * keyBlocksY;   // every tile has a record: no tile rows are launched
         t.plan = *plan; t.plan.prev_stats = nullptr; t.plan.prev_realtime = nullptr; t.plan.prev_waves = 0;
         if (tiles_out) *tiles_out = T + F;
         if (pieces_out) *pieces_out = nPieces + F;
@@ -893,9 +918,10 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
     RTS_HIP(hipSetDevice(c->device));
     clearSplits(c);
     int status = RTS_OK;
-    auto median5 = [&](float* out) {          // two untimed launches, then the median of five
-        float times[5];
-        for (int i = -2; i < 5; ++i) {
+    int reps = 5;                              // (nine for the tables of a dispatch below 0.1 ms: its launches are cheap, its noise is not)
+    auto median5 = [&](float* out) {          // two untimed launches, then the median of five (or nine)
+        float times[9];
+        for (int i = -2; i < reps; ++i) {
             hipError_t e = hipEventRecord(c->ev0, nullptr);
             if (e != hipSuccess) { status = hipStatus(e); return false; }
             status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
@@ -907,8 +933,8 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
             if (e != hipSuccess) { status = hipStatus(e); return false; }
             if (i >= 0) times[i] = ms;
         }
-        for (int i = 1; i < 5; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
-        *out = times[2];
+        for (int i = 1; i < reps; ++i) for (int j = i; j > 0 && times[j] < times[j - 1]; --j) { float t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
+        *out = times[reps / 2];
         return true;
     };
     // (the wide kernel first, and a later candidate must beat the best by 2 %: at equal frame time the wide kernel's waves
@@ -944,46 +970,77 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
         }
         // third stage: split tables.  Tiles that lived longer than a share of the dispatch and ended in its later part.
         if (c->wideCount && c->blockWaves == 1 && !c->wideLane && (!light || light->nsamples <= 1) && c->useSplits) {
-            // Three tables (profiles/r04/front_tiles_sweep.log): the longest third of the tiles started first and the tiles that lived
-            // longer than a quarter of the dispatch (and 20 us) split into pieces of a tenth of it; the front tiles alone; the splits
-            // alone with a lower threshold.
+            // Seven tables from ONE set of wave statistics (profiles/r04/front_tiles_sweep.log, whole_dispatch_order.log): the tiles
+            // that lived longer than max(T/4, 20 us) and ended in the second half split into pieces of max(T/10, 8 us) -- or none
+            // split --, with the longest 3 % / third / ALL of the tiles started first (all: the whole dispatch in table order, no
+            // tile rows at all); and the splits alone with a lower threshold.  A frame whose time is a few long waves wants the
+            // first kind (atrium), a throughput-bound one a short front list (city) or the table order (courtyard), the stripe of
+            // a multi-GPU frame both.
             const float T = bestMs * 1000.f;                                      // us
-            const int trials = 3;
+            if (bestMs < 0.1f) { reps = 9; if (!median5(&bestMs)) return giveUp(); }   // (the plain launch once more, by the same measure)
+            const int trials = 7;
             int kept = -1, installed = -1;
             rts_split_plan plan{};
+            std::vector<uint64_t> tuneStats, tuneRt;
+            status = measureDispatch(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, tuneStats, tuneRt);
+            if (status == RTS_ERR_INVALID_ARG) { status = RTS_OK; goto tuned; }    // (not a dispatch of 8x8 tiles: no table)
+            if (status != RTS_OK) return giveUp();
+            {
             auto fill = [&](int i) {
                 plan = rts_split_plan{};
                 plan.max_pieces = 8;
                 plan.max_tiles = 8192;
-                if (i == 0) {
-                    plan.min_life_us = 0.25f * T < 20.f ? 20.f : 0.25f * T; plan.end_after_us = 0.5f * T;
-                    plan.piece_us = 0.1f * T < 8.f ? 8.f : 0.1f * T; plan.front_share = 1.f / 3.f;
-                } else if (i == 1) {
-                    plan.min_life_us = 1e9f; plan.piece_us = 1e9f; plan.front_share = 1.f / 3.f;
+                plan.prev_stats = tuneStats.data(); plan.prev_realtime = tuneRt.data(); plan.prev_waves = tuneStats.size() / 4;
+                static const float share[3] = { 0.03f, 1.f / 3.f, 1.f };
+                if (i < 6) {
+                    plan.front_share = share[i % 3];
+                    if (i < 3) {
+                        plan.min_life_us = 0.25f * T < 20.f ? 20.f : 0.25f * T; plan.end_after_us = 0.5f * T;
+                        plan.piece_us = 0.1f * T < 8.f ? 8.f : 0.1f * T;
+                    } else { plan.min_life_us = 1e9f; plan.piece_us = 1e9f; }
                 } else {
                     plan.min_life_us = 0.15f * T < 8.f ? 8.f : 0.15f * T; plan.end_after_us = 0.5f * T; plan.piece_us = plan.min_life_us * 0.5f;
                 }
             };
-            float tableMs = 1e30f;
-            for (int i = 0; i < trials; ++i) {                                     // all three are timed; the fastest is the candidate
+            // Every table is timed against the PLAIN launch measured right beside it (planning leaves the device idle for
+            // milliseconds and its clocks drop: a figure from before the planning is not comparable; 20 ms of the launch itself
+            // first).  The table with the best ratio is the candidate; it must gain 1.5 %.
+            float bestRatio = 1e30f, tableMs = bestMs;
+            for (int i = 0; i < trials; ++i) {
                 fill(i);
                 uint32_t tiles = 0;
                 status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, &tiles, nullptr);
                 if (status != RTS_OK) return giveUp();
                 installed = i;
                 if (!tiles) continue;
+                for (const auto t0 = std::chrono::steady_clock::now(); status == RTS_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20);) {
+                    for (int w = 0; w < 8 && status == RTS_OK; ++w)
+                        status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+                    if (hipStreamSynchronize(nullptr) != hipSuccess) status = RTS_ERR_HIP;
+                }
+                if (status != RTS_OK) return giveUp();
+                float plainMs;
                 if (!median5(&ms)) return giveUp();
-                if (ms < tableMs) { tableMs = ms; kept = i; }
+                c->useSplits = 0;
+                const bool ok = median5(&plainMs);
+                c->useSplits = 1;
+                if (!ok) return giveUp();
+                if (getenv("RTS_TUNE_LOG"))           // diagnostics: what the tuner saw
+                    fprintf(stderr, "rts tune: table %d (life > %.1f us, front share %.2f): %u split + %u front tiles, %.4f ms against %.4f plain beside it\n", i,
+                            plan.min_life_us, plan.front_share, c->splits.nTiles, c->splits.nFront, ms, plainMs);
+                if (ms / plainMs < bestRatio) { bestRatio = ms / plainMs; tableMs = ms; kept = i; }
             }
-            if (kept >= 0 && tableMs < bestMs * 0.985f) bestMs = tableMs; else kept = -1;
+            if (kept >= 0 && bestRatio < 0.985f) bestMs = tableMs; else kept = -1;
             if (kept < 0) clearSplits(c);
             else if (kept != installed) {
                 fill(kept);
                 status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, nullptr, nullptr);
                 if (status != RTS_OK) return giveUp();
             }
+            }
         }
     }
+tuned:
     if (chosen) *chosen = best;
     if (ms_out) *ms_out = bestMs;
     return RTS_OK;

@@ -73,6 +73,7 @@ struct TraceParams {
     uint32_t* pieceLog;       // split planning only: per piece 1 + pieceLogCap dwords {count, node indices visited ...}
     uint64_t* pieceClock;     // diagnostics ("piece_stats"): per piece {100 MHz clock at its start, at its end}, or NULL
     uint32_t nPieces, pieceLogCap;
+    uint32_t allInTable;      // every tile of the dispatch has a record: the grid is the records alone (no tile rows at all)
     float offsets[64][4];
 };
 

@@ -1431,8 +1431,10 @@ void shadowMaskPacketKernel(TraceParams p) {
     const uint32_t ns = SOFT ? p.nsamples : 1u;
     // clock probe (every instantiation, so that the clock is measured on the launches that are timed): one wave per tile row
     // (the stamps go straight to memory: nothing of the probe stays in registers across the walk)
-    const uint32_t probeRow = TILESPLIT ? blockIdx.y - p.pieceRows : (p.grid2d ? blockIdx.y : 0u);   // (read under p.clockProbe only)
-    const bool probed = p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && (!TILESPLIT || blockIdx.y >= p.pieceRows);
+    // (with a table: the tile rows stamp; when the table holds every tile there are none, and the front-tile rows stamp instead)
+    const uint32_t probeRow = TILESPLIT ? (p.allInTable ? blockIdx.y : blockIdx.y - p.pieceRows) : (p.grid2d ? blockIdx.y : 0u);
+    const bool probed = p.clockProbe != nullptr && blockIdx.x == 0 && threadIdx.x == 0 &&
+                        (!TILESPLIT || (p.allInTable ? blockIdx.y < p.blocksY : blockIdx.y >= p.pieceRows));
     if (probed) {
         uint64_t* o = p.clockProbe + (size_t)probeRow * 4;
         o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
@@ -1570,7 +1572,8 @@ void tileShape(int variant, int wavesPerBlock, uint32_t* blockW, uint32_t* block
 
 hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p, hipStream_t stream, uint32_t ldsPad) {
     dim3 grid(p.gridBlocks), block(256);
-    if (p.grid2d) grid = dim3(p.blocksX, p.blocksY + (p.pieces ? p.pieceRows : 0u));   // (the pieces of split tiles come first)
+    // (the records of a split table come first; when every tile has a record there are no tile rows at all)
+    if (p.grid2d) grid = dim3(p.blocksX, (p.pieces && p.allInTable ? 0u : p.blocksY) + (p.pieces ? p.pieceRows : 0u));
     const bool soft = p.nsamples > 1;
     if (variant == V_WIDE && wavesPerBlock == 4) {                       // 2 x 2 tiles per workgroup: neighbours share the scalar cache
         if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 4, false, true, false, 1>), grid, block, 0, stream, p);

@@ -76,13 +76,15 @@ for cfg in sys.argv[1:] or ["atrium_1080p"]:
             for life, piece, maxp, *rest in PLANS:
                 endfrac = rest[0] if rest else 0.0           # tiles that ended later than this fraction of the plain frame
                 front = rest[1] if len(rest) > 1 else 0.0     # front_life_us
+                share = rest[2] if len(rest) > 2 else 0.0     # front_share
                 t0 = time.perf_counter()
                 tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_m, light=wl.light, min_life_us=life, piece_us=piece, max_pieces=int(maxp),
-                                                end_after_us=endfrac * med * 1e3, front_life_us=front, stripes=STRIPE)
+                                                end_after_us=endfrac * med * 1e3, front_life_us=front, front_share=share, stripes=STRIPE,
+                                                max_tiles=int(os.environ.get("MAXTILES", 0)))
                 plan_ms = (time.perf_counter() - t0) * 1e3
                 bad = check()
                 med2, mn2, b2b2 = timeit(ctx, go, N)
-                print(f"{cfg} kernel {k} table life>{life:g}us end>{endfrac:g}T piece {piece:g}us max {int(maxp)} front>{front:g}us: {tiles} tiles, {pieces} pieces (planned in {plan_ms:.0f} ms): "
+                print(f"{cfg} kernel {k} table life>{life:g}us end>{endfrac:g}T piece {piece:g}us max {int(maxp)} front>{front:g}us/{share:g}: {tiles} tiles, {pieces} pieces (planned in {plan_ms:.0f} ms): "
                       f"median {med2:.4f} ms ({(med2 / med - 1) * 100:+.1f} %), min {mn2:.4f}, back to back {b2b2:.4f}; {bad} bytes differ", flush=True)
             ctx.clear_splits()
         ctx.free(d_pos); ctx.free(d_m)
