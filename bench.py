@@ -275,7 +275,7 @@ def pmc_child(args):
         n_plan, table = 0, None
         if args.splits:                                          # the split table of the tuning child, planned again here
             table = apply_splits(ctx, args.splits, wl, d_pos, d_mask)
-            n_plan = 3 if table else 2                           # 2 launches with wave statistics (+ the planning walk)
+            n_plan = 3 if (table and table["split_tiles"]) else 2   # 2 launches with wave statistics (+ the planning walk of the tiles to split)
         n_pre = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < args.prewarm_seconds:   # only the kernel-trace pass asks for one (durations)
