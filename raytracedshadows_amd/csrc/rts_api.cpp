@@ -813,6 +813,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         std::sort(sel.begin(), sel.end(), longer);
         // front tiles: longest first in half-octaves of life, image order inside one (neighbouring tiles walk the same part of
         // the tree: started together they share the scalar cache and the L2 as in the plain launch)
+        // (0.5 / 1 / 2 / 4 bands per octave and the exact order measured: profiles/r04/table_order_bands.log -- 2 and 4 are level)
         const auto band = [](float us) { return (int)std::floor(std::log2(us < 0.25f ? 0.25f : us) * 2.f); };
         std::sort(front.begin(), front.end(), [&](const Sel& a, const Sel& b) {
             const int ba = band(a.us), bb = band(b.us);
@@ -1004,7 +1005,7 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
             };
             // Every table is timed against the PLAIN launch measured right beside it (planning leaves the device idle for
             // milliseconds and its clocks drop: a figure from before the planning is not comparable; 20 ms of the launch itself
-            // first).  The table with the best ratio is the candidate; it must gain 1.5 %.
+            // first).  The table with the best ratio is the candidate; it must gain 1 %.
             float bestRatio = 1e30f, tableMs = bestMs;
             for (int i = 0; i < trials; ++i) {
                 fill(i);
@@ -1030,7 +1031,7 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
                             plan.min_life_us, plan.front_share, c->splits.nTiles, c->splits.nFront, ms, plainMs);
                 if (ms / plainMs < bestRatio) { bestRatio = ms / plainMs; tableMs = ms; kept = i; }
             }
-            if (kept >= 0 && bestRatio < 0.985f) bestMs = tableMs; else kept = -1;
+            if (kept >= 0 && bestRatio < 0.99f) bestMs = tableMs; else kept = -1;    // (paired figures: 1 % is outside their noise)
             if (kept < 0) clearSplits(c);
             else if (kept != installed) {
                 fill(kept);

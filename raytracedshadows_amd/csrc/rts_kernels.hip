@@ -1395,6 +1395,7 @@ void shadowMaskPacketKernel(TraceParams p) {
             const uint32_t bit = by * blocksX + bx;
             const uint32_t word = *(ConstU32Ptr)(uintptr_t)(mapAddr + (uint64_t)(bit >> 5) * 4u);
             mine = !((word >> (bit & 31u)) & 1u);                    // a tile of the table is walked by its record(s) at the head
+            if (!mine) return;                                       // (a scalar branch: nothing of this wave is needed)
         }
     } else by = dispatchRow(p, blockIdx.y);                           // (PLAIN: a 2-D grid, rows in dispatchRow order)
     if (!PLAIN && !blockToXY(p, blockIdx.x, &bx, &by)) return;
