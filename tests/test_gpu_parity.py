@@ -550,6 +550,19 @@ def test_split_tables_never_change_the_mask(ctx):
             ctx.synchronize()
             ctx.d2h(got, d_mask)
             assert (got[64:200] == want[64:200]).all() and (got[:64] == 9).all() and (got[200:] == 9).all()
+            # ... unless the table was planned FOR that row range (what a rank with a contiguous stripe does)
+            tiles_rr, _ = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=15.0, piece_us=5.0, max_pieces=8,
+                                          front_share=1.0, row_begin=64, row_end=200)
+            assert tiles_rr == ((W + 7) // 8) * ((200 - 64) // 8)
+            got = np.full((H, W), 9, np.uint8)
+            ctx.h2d(d_mask, got)
+            ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=wl.light, row_begin=64, row_end=200)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            assert (got[64:200] == want[64:200]).all() and (got[:64] == 9).all() and (got[200:] == 9).all()
+            assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()          # (the full frame: another dispatch, no table)
+            tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=15.0, piece_us=5.0, max_pieces=8,
+                                            end_after_us=40.0)
             # "tile_splits" 0 ignores the table
             ctx.set_option("tile_splits", 0)
             assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()
@@ -1099,6 +1112,21 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                 got = ctx.trace_shadow_mask(k, pos, W, H, light=light)
                 bad = int((got != want).sum())
                 assert bad == 0, (seed, n, W, H, kernel, "light", lights.index(light), bad)
+                # ... through a split table with random thresholds (one-sample lights, the two packet kernels, one-tile workgroups)
+                if kernel in (3, 8) and (light is None or light.nsamples <= 1) and ctx.get_option("wide_nodes") > 0:
+                    ctx.set_option("block_waves", 1)
+                    ctx.set_option("wide_lane", 0)
+                    ctx.h2d(d_pos, pos)
+                    tiles, _ = ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, min_life_us=float(rs.choice([0.3, 1.0, 3.0])),
+                                               piece_us=float(rs.choice([0.2, 1.0])), max_pieces=int(rs.choice([2, 5, 16])),
+                                               front_share=float(rs.choice([0.0, 0.4, 1.0])))
+                    got = np.full((H, W), 9, np.uint8)
+                    ctx.h2d(d_mask, got)
+                    ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)
+                    ctx.synchronize()
+                    ctx.d2h(got, d_mask)
+                    ctx.clear_splits()
+                    assert (got == want).all(), (seed, kernel, "split table", tiles, int((got != want).sum()))
                 # ... and as row stripes (contiguous through the host-pointer entry; 32-row interleaved bands in one dispatch)
                 ns = int(rs.randint(2, 5))
                 got = np.full((H, W), 9, np.uint8)
