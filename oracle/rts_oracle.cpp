@@ -213,6 +213,22 @@ static inline bool rayTri(V3 o, float tmax, V3 d, V3 v0, V3 e0, V3 e1) {
     return true;
 }
 
+// The same test, telling WHERE the disjunction of rejects first holds (for counting what a wave-wide early-out would skip):
+// 0 hit, 1 b1 out of [0, 1], 2 b2 < 0 or b1 + b2 > 1, 3 t out of [0, tmax].  rayTri(...) == (rayTriStage(...) == 0).
+static inline int rayTriStage(V3 o, float tmax, V3 d, V3 v0, V3 e0, V3 e1) {
+    V3 s1 = crossv(d, e1);
+    float invd = 1.0f / dotv(s1, e0);
+    V3 dd = subv(o, v0);
+    float b1 = dotv(dd, s1) * invd;
+    V3 s2 = crossv(dd, e0);
+    float b2 = dotv(d, s2) * invd;
+    float t = dotv(e1, s2) * invd;
+    if (b1 < 0.0f || b1 > 1.0f) return 1;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return 2;
+    if (t < 0.0f || t > tmax) return 3;
+    return 0;
+}
+
 // comp:61-73
 static inline bool rayBox(V3 o, V3 invdir, V3 pmin, V3 pmax) {
     float fx = (pmax.x - o.x) * invdir.x, fy = (pmax.y - o.y) * invdir.y, fz = (pmax.z - o.z) * invdir.z;
@@ -834,7 +850,9 @@ extern "C" void orc_order_experiment(const uint32_t* packed, const float* consta
 // VALU), out[3] member lanes summed over those tests, out[4] triangle tests (wave-wide), out[5] member lanes over them,
 // out[6] longest tile (steps), out[7] mismatches, out[8] box tests if a slot repeating the previous slot's box is
 // not tested again, out[9] sum over tiles of steps^2 (for the spread), out[10] rays whose 1/d is not finite-nonzero
-// (excluded: the product sends such waves to the exact lane-per-ray walk).
+// (excluded: the product sends such waves to the exact lane-per-ray walk); out[13] wave-wide triangle tests in which EVERY
+// participating ray is rejected by the b1 condition alone, out[14] ... by the b1 / b2 / b1 + b2 conditions (no ray reaches the
+// test of t), out[15] ... in which no ray hits.
 // hist (nullable): 64 bins of steps per tile, bin = min(63, steps / histStep).
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -872,6 +890,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
     uint64_t violations = 0, falsePos = 0;
     float rootLo[3] = { u2f(bvh[0]), u2f(bvh[1]), u2f(bvh[2]) }, rootHi[3] = { u2f(bvh[4]), u2f(bvh[5]), u2f(bvh[6]) };
     uint64_t tiles = 0, steps = 0, boxT = 0, boxLanes = 0, triT = 0, triLanes = 0, longest = 0, mism = 0, boxD = 0, sq = 0, unsafe = 0;
+    uint64_t allB1 = 0, allBary = 0, allMiss = 0;
     const uint32_t tx = W / 8, ty = H / 8;
     std::vector<uint64_t> histAll(64, 0);
 #ifdef _OPENMP
@@ -882,7 +901,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
         std::vector<WSlot> slots;
         std::vector<std::pair<u32, uint64_t>> stack;
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4) reduction(+ : tiles, steps, boxT, boxLanes, triT, triLanes, mism, boxD, sq, unsafe, violations, falsePos) reduction(max : longest)
+#pragma omp for schedule(dynamic, 4) reduction(+ : tiles, steps, boxT, boxLanes, triT, triLanes, mism, boxD, sq, unsafe, violations, falsePos, allB1, allBary, allMiss) reduction(max : longest)
 #endif
         for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
             const uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
@@ -983,6 +1002,17 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                     if (!h) continue;
                     if (s.leaf) {
                         ++triT; triLanes += __builtin_popcountll(h);
+                        {
+                            const u32* a = bvh + (size_t)s.ref * 8; const u32* tt = bvh + (size_t)a[3] * 4;
+                            const V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(a[4]), u2f(a[5]), u2f(a[6]) }, v0 = { u2f(tt[0]), u2f(tt[1]), u2f(tt[2]) };
+                            int worst = 3, best = 1;            // stages over the participating rays (1 = b1 ... 0 = hit)
+                            bool hitAny = false;
+                            for (u32 l = 0; l < 64; ++l) if ((h >> l) & 1) {
+                                const int st = rayTriStage(o[l], tm[l], d[l], v0, e0, e1);
+                                if (st == 0) hitAny = true; else { if (st > best) best = st; if (st < worst) worst = st; }
+                            }
+                            if (!hitAny) { ++allMiss; if (best == 1) ++allB1; if (best <= 2) ++allBary; }
+                        }
                         for (u32 l = 0; l < 64; ++l) if (((h >> l) & 1) && tri(s.ref, l)) {
                             // cheap mode: the hit counts only if the ray hits the box of the leaf's parent (exact form)
                             const u32 parentBox = s.boxNode != kInvalid ? s.boxNode : n;
@@ -1004,5 +1034,6 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
     }
     out[0] = tiles; out[1] = steps; out[2] = boxT; out[3] = boxLanes; out[4] = triT; out[5] = triLanes; out[6] = longest;
     out[7] = mism; out[8] = boxD; out[9] = sq; out[10] = unsafe; out[11] = violations; out[12] = falsePos;
+    out[13] = allB1; out[14] = allBary; out[15] = allMiss;
     if (hist) for (int i = 0; i < 64; ++i) hist[i] = histAll[i];
 }

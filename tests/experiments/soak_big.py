@@ -12,6 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 t0 = time.time()
 cases = 0
+tables = 0
 with api.ShadowContext(0) as ctx:
     while time.time() - t0 < budget:
         kind = rs.randint(0, 8)
@@ -63,6 +64,32 @@ with api.ShadowContext(0) as ctx:
                 ctx.d2h(got, d_mask)
                 bad = int((got != want).sum())
                 assert bad == 0, (cases, sc.name, producer, W, H, kernel, spp, n, bad)
+                # round 4: the same dispatch(es) through a split table with random thresholds, or the tuner's own choice
+                if kernel in (3, 8) and spp == 1 and ctx.get_option("wide_nodes") > 0:
+                    ctx.set_option("block_waves", 1); ctx.set_option("wide_lane", 0); ctx.set_option("xcd_swizzle", 0)
+                    got = np.full((H, W), 7, np.uint8)
+                    ctx.h2d(d_mask, got)
+                    for s in range(n):
+                        stripes = None if n == 1 else (band, n, s)
+                        if rs.rand() < 0.25:
+                            ctx.autotune(k, d_pos, W, H, d_mask, light=light, stripes=stripes)
+                            ctx.h2d(d_mask, got) if s == 0 else None
+                        else:
+                            ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, stripes=stripes, min_life_us=float(rs.choice([2.0, 8.0, 30.0, 1e9])),
+                                            piece_us=float(rs.choice([1.0, 4.0, 12.0])), max_pieces=int(rs.choice([2, 4, 8, 16])),
+                                            end_after_us=float(rs.choice([0.0, 0.0, 20.0])), front_share=float(rs.choice([0.0, 0.03, 0.33, 1.0])),
+                                            front_life_us=0.0, max_tiles=int(rs.choice([0, 64, 8192])))
+                        if n == 1:
+                            ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)
+                        else:
+                            ctx.trace_shadow_mask_stripes_device(k, d_pos, W, H, d_mask, band, n, s, light=light)
+                        tables += 1 if ctx.get_option("split_pieces") else 0
+                    ctx.synchronize()
+                    ctx.d2h(got, d_mask)
+                    ctx.clear_splits()
+                    ctx.set_option("kernel", kernel)
+                    bad = int((got != want).sum())
+                    assert bad == 0, (cases, sc.name, producer, W, H, kernel, "split table", n, bad)
         finally:
             ctx.free(d_pos); ctx.free(d_mask)
             for key, v in (("kernel", -1), ("packet_budget", 16), ("packet_share", 4), ("block_waves", 1), ("xcd_swizzle", 0), ("row_order", 0), ("wide_lane", 1), ("soft_split", 1)):
@@ -70,4 +97,5 @@ with api.ShadowContext(0) as ctx:
         cases += 1
         if cases % 5 == 0:
             print(f"{cases} big cases ok ({time.time() - t0:.0f}s)", flush=True)
-print(f"soak_big: {cases} random large frames x 6 kernels incl. both wide ones (random knobs, stripes, 1-16 samples, per-pixel jitter, host- and GPU-built streams) all bit-exact ({time.time() - t0:.0f}s)")
+print(f"soak_big: {cases} random large frames x 6 kernels incl. both wide ones (random knobs, stripes, 1-16 samples, per-pixel jitter, host- and GPU-built streams) "
+      f"and {tables} dispatches through split tables (random plans or the tuner's) all bit-exact ({time.time() - t0:.0f}s)")
