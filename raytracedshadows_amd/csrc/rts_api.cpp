@@ -368,6 +368,12 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     return RTS_ERR_INVALID_ARG;
 }
 
+// Diagnostics (RTS_TUNE_LOG set): why the planner refused.
+static int planRefused(const char* why) {
+    if (getenv("RTS_TUNE_LOG")) fprintf(stderr, "[rts plan] refused: %s\n", why);
+    return RTS_ERR_INVALID_ARG;
+}
+
 static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions,
                          uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end, uint32_t band_rows,
                          uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, void* stream) {
@@ -445,7 +451,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
     if (c->planning) {                       // pieces only: the planning walk of the selected tiles, with visit logs
         if (!(variant == rts::V_PACKET || variant == rts::V_WIDE) || c->blockWaves != 1 || p.nsamples != 1 || !p.grid2d || !p.wide ||
             (n_stripes > 1 && p.bandShift == 0xFFFFFFFFu))
-            return RTS_ERR_INVALID_ARG;
+            return planRefused("the planning walk needs a one-tile packet kernel, one sample, a 2-D grid, the private copy");
         p.waveStats = nullptr; p.waveRealtime = nullptr; p.clockProbe = nullptr; p.rowOrder = 0;
         p.skipMap = c->planning->d_pieces;   // (never read: no tile rows in this launch)
         p.pieces = c->planning->d_pieces; p.nPieces = c->planning->nPieces; p.pieceRows = c->planning->pieceRows;
@@ -736,7 +742,7 @@ static int measureDispatch(rts_ctx* c, const rts_constants* k, const rts_light* 
             status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
         c->useSplits = use;
         if (status == RTS_OK) e = hipDeviceSynchronize();
-        if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = RTS_ERR_INVALID_ARG;   // not an 8x8-tile kernel
+        if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = planRefused("not a dispatch of 8x8 tiles");
         if (status == RTS_OK && e == hipSuccess) {
             stats.resize(waves * 4); rt.resize(waves * 4);
             e = hipMemcpy(stats.data(), c->d_waveStats, waves * 32, hipMemcpyDeviceToHost);
@@ -757,11 +763,12 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
     if (pieces_out) *pieces_out = 0;
     if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f) || !(plan->end_after_us >= 0.f) ||
         !(plan->front_life_us >= 0.f) || plan->front_life_us > plan->min_life_us || !(plan->front_share >= 0.f) || plan->front_share > 1.f)
-        return RTS_ERR_INVALID_ARG;
-    if (light && light->nsamples > 1) return RTS_ERR_INVALID_ARG;               // (soft shadows are dealt over waves by "soft_split")
+        return planRefused("arguments");
+    if (light && light->nsamples > 1) return planRefused("more than one light sample");   // (soft shadows are dealt over waves by "soft_split")
     RTS_HIP(hipSetDevice(c->device));
     clearSplits(c);
     if (!c->wideCount) return RTS_OK;                                            // pieces walk the private copy: none, no table
+    if (n_stripes > 1 && stripe >= (H + band_rows - 1) / band_rows) return RTS_OK;   // a stripe without a band: nothing to launch, no table
     const uint32_t maxPieces = plan->max_pieces < 2 ? 2 : (plan->max_pieces > 64 ? 64 : plan->max_pieces);
     const uint32_t maxTiles = plan->max_tiles ? (plan->max_tiles > 65536u ? 65536u : plan->max_tiles) : 4096u;
     const uint32_t logCap = 16384;
@@ -840,7 +847,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         uint32_t rows = row_end - row_begin;
         if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
         const uint32_t keyBlocksY = (rows + 7) / 8;
-        if (blocksY > keyBlocksY) return RTS_ERR_INVALID_ARG;                     // statistics of another dispatch
+        if (blocksY > keyBlocksY) return planRefused("statistics of another dispatch");
         std::vector<uint32_t> bitmap(((size_t)blocksX * keyBlocksY + 31) / 32 + 1, 0u);
         std::vector<uint32_t> frontRecords((size_t)F * 8, 0u);                   // {tile, 0, END, 0 = "front tile", 0...}
         for (uint32_t t = 0; t < T + F; ++t) {

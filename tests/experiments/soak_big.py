@@ -71,14 +71,20 @@ with api.ShadowContext(0) as ctx:
                     ctx.h2d(d_mask, got)
                     for s in range(n):
                         stripes = None if n == 1 else (band, n, s)
+                        ctx.set_option("kernel", kernel)           # (the tuner installs its own pick, maybe lane-per-ray: no table then)
                         if rs.rand() < 0.25:
                             ctx.autotune(k, d_pos, W, H, d_mask, light=light, stripes=stripes)
                             ctx.h2d(d_mask, got) if s == 0 else None
                         else:
-                            ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, stripes=stripes, min_life_us=float(rs.choice([2.0, 8.0, 30.0, 1e9])),
-                                            piece_us=float(rs.choice([1.0, 4.0, 12.0])), max_pieces=int(rs.choice([2, 4, 8, 16])),
-                                            end_after_us=float(rs.choice([0.0, 0.0, 20.0])), front_share=float(rs.choice([0.0, 0.03, 0.33, 1.0])),
-                                            front_life_us=0.0, max_tiles=int(rs.choice([0, 64, 8192])))
+                            plan = dict(min_life_us=float(rs.choice([2.0, 8.0, 30.0, 1e9])),
+                                        piece_us=float(rs.choice([1.0, 4.0, 12.0])), max_pieces=int(rs.choice([2, 4, 8, 16])),
+                                        end_after_us=float(rs.choice([0.0, 0.0, 20.0])), front_share=float(rs.choice([0.0, 0.03, 0.33, 1.0])),
+                                        front_life_us=0.0, max_tiles=int(rs.choice([0, 64, 8192])))
+                            try:
+                                ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, stripes=stripes, **plan)
+                            except Exception:
+                                print("plan_splits failed:", cases, sc.name, producer, W, H, kernel, stripes, plan, flush=True)
+                                raise
                         if n == 1:
                             ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)
                         else:
