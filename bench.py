@@ -362,7 +362,7 @@ def splits_arg(plan):
     if not plan:
         return ""
     return (":".join(repr(float(plan.get(k, 0.0))) for k in ("min_life_us", "end_after_us", "piece_us", "front_life_us", "front_share"))
-            + f":{int(plan['max_pieces'])}:{int(plan.get('max_tiles', 0))}")
+            + f":{int(plan['max_pieces'])}:{int(plan.get('max_tiles', 0))}:{int(plan.get('xcd_square', 0))}:{int(plan.get('life_block', 0))}")
 
 
 def parse_splits(text):
@@ -370,7 +370,7 @@ def parse_splits(text):
         return None
     f = text.split(":")
     return {"min_life_us": float(f[0]), "end_after_us": float(f[1]), "piece_us": float(f[2]), "front_life_us": float(f[3]),
-            "front_share": float(f[4]), "max_pieces": int(f[5]), "max_tiles": int(f[6])}
+            "front_share": float(f[4]), "max_pieces": int(f[5]), "max_tiles": int(f[6]), "xcd_square": int(f[7]) if len(f) > 7 else 0, "life_block": int(f[8]) if len(f) > 8 else 0}
 
 
 def apply_splits(ctx, plan, wl, d_pos, d_mask, stripes=None):
@@ -381,7 +381,7 @@ def apply_splits(ctx, plan, wl, d_pos, d_mask, stripes=None):
     tiles, records = ctx.plan_splits(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, min_life_us=plan["min_life_us"],
                                      end_after_us=plan["end_after_us"], piece_us=plan["piece_us"], max_pieces=plan["max_pieces"],
                                      front_life_us=plan.get("front_life_us", 0.0), front_share=plan.get("front_share", 0.0),
-                                     max_tiles=plan.get("max_tiles", 0), stripes=stripes)
+                                     max_tiles=plan.get("max_tiles", 0), xcd_square=plan.get("xcd_square", 0), life_block=plan.get("life_block", 0), stripes=stripes)
     return table_size(ctx) if tiles else None
 
 
@@ -495,7 +495,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = what rts_ctx_autotune picks for the frame)")
     ap.add_argument("--options", default="", help="context options for the traced frame, key=value,... (with --kernel; else what "
                                                   "rts_ctx_autotune picks: packet_share, row_order)")
-    ap.add_argument("--splits", default="", help="split table for the traced frame, min_life_us:end_after_us:piece_us:front_life_us:front_share:max_pieces:max_tiles (with "
+    ap.add_argument("--splits", default="", help="split table for the traced frame, min_life_us:end_after_us:piece_us:front_life_us:front_share:max_pieces:max_tiles[:xcd_square[:life_block]] (with "
                                                  "--kernel; else what rts_ctx_autotune keeps)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)

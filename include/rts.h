@@ -301,6 +301,15 @@ typedef struct rts_split_plan {
                                     tile rows are launched at all.  rts_ctx_autotune tries 0.03, 1/3 and 1 */
     uint32_t max_pieces;         /* 2..64 */
     uint32_t max_tiles;          /* 0 = 4096 */
+    uint32_t xcd_square;         /* 0, or S: inside a band of the front order, record i (which the dispatcher places on XCD i mod 8) is taken
+                                    from the S x S-tile squares of the image that belong to that XCD -- each XCD's L2 then holds the part of
+                                    the tree its squares see.  Balanced by construction (equal numbers of equally long tiles per XCD);
+                                    rts_ctx_autotune uses 32 with front_share 1 */
+    uint32_t life_block;         /* 0 / 1, or B: the front order takes a tile to be as long as the longest tile of its block of B x B tiles.
+                                    A table sorted by single tiles fits ONE camera (a step of 0.1 % of the view distance moves what is long by
+                                    a tile, and a stale order is slower than none); sorted by blocks of 16 it gives up a third of its gain
+                                    and keeps the rest over a camera path (rts_ctx option "tune_for_motion") */
+    uint32_t reserved_;          /* 0 */
     const uint64_t* prev_stats;  /* all three NULL / 0: measure now */
     const uint64_t* prev_realtime;
     size_t   prev_waves;

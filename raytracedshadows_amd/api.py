@@ -156,7 +156,7 @@ _sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
 class SplitPlan(C.Structure):
     """rts_split_plan (include/rts.h)."""
     _fields_ = [("min_life_us", C.c_float), ("end_after_us", C.c_float), ("piece_us", C.c_float), ("front_life_us", C.c_float), ("front_share", C.c_float), ("max_pieces", C.c_uint32), ("max_tiles", C.c_uint32),
-                ("prev_stats", C.c_void_p), ("prev_realtime", C.c_void_p), ("prev_waves", C.c_size_t)]
+                ("xcd_square", C.c_uint32), ("life_block", C.c_uint32), ("reserved_", C.c_uint32), ("prev_stats", C.c_void_p), ("prev_realtime", C.c_void_p), ("prev_waves", C.c_size_t)]
 
 
 _sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32, C.c_uint32,
@@ -462,14 +462,15 @@ class ShadowContext:
             return None
         return {"min_life_us": float(plan.min_life_us), "end_after_us": float(plan.end_after_us), "piece_us": float(plan.piece_us),
                 "front_life_us": float(plan.front_life_us), "front_share": float(plan.front_share), "max_pieces": int(plan.max_pieces),
-                "max_tiles": int(plan.max_tiles)}
+                "max_tiles": int(plan.max_tiles), "xcd_square": int(plan.xcd_square), "life_block": int(plan.life_block)}
 
     def plan_splits(self, constants, d_positions, width, height, d_mask, light=None, min_life_us=20.0, piece_us=10.0,
-                    max_pieces=8, max_tiles=0, row_begin=0, row_end=None, stripes=None, prev=None, end_after_us=0.0, front_life_us=0.0, front_share=0.0):
+                    max_pieces=8, max_tiles=0, row_begin=0, row_end=None, stripes=None, prev=None, end_after_us=0.0, front_life_us=0.0, front_share=0.0,
+                    xcd_square=0, life_block=0):
         """rts_ctx_plan_splits(_stripes): measures the dispatch, installs the split table; returns (tiles, pieces).
         stripes = (band_rows, n_stripes, stripe) plans the interleaved-stripe dispatch; prev = (stats, realtime) arrays of an
         earlier frame (read_wave_stats / read_wave_realtime) instead of a measuring launch."""
-        plan = SplitPlan(min_life_us, end_after_us, piece_us, front_life_us, front_share, max_pieces, max_tiles, None, None, 0)
+        plan = SplitPlan(min_life_us, end_after_us, piece_us, front_life_us, front_share, max_pieces, max_tiles, xcd_square, life_block, 0, None, None, 0)
         keep = None
         if prev is not None:
             keep = (np.ascontiguousarray(prev[0], np.uint64), np.ascontiguousarray(prev[1], np.uint64))

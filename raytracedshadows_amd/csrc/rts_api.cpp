@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 using rts::TraceParams;
@@ -57,6 +58,8 @@ struct rts_ctx {
         uint32_t W = 0, H = 0, rowBegin = 0, rowEnd = 0, bandRows = 0, nStripes = 0, stripe = 0, blocksX = 0, blocksY = 0;
         uint32_t* d_skipMap = nullptr;       // one bit per tile of the dispatch
         uint32_t* d_pieces = nullptr;        // 8 dwords per piece
+        uint32_t* d_frontMap = nullptr;      // one dword per record, XCD-major (TraceParams::frontMap)
+        uint32_t frontStride = 0;
         uint32_t nPieces = 0, pieceRows = 0, nTiles = 0, nFront = 0;      // records (pieces + front tiles), split tiles, front tiles
         bool allTiles = false;
         rts_split_plan plan{};               // what the table was planned with (rts_ctx_get_split_plan)
@@ -65,6 +68,7 @@ struct rts_ctx {
         std::vector<std::pair<void*, uint64_t*>> state;
     } splits;
     int useSplits = 1;                       // option "tile_splits": 0 ignores an installed table
+    int tuneForMotion = 0;                   // option "tune_for_motion": the tuner's tables must survive a camera path
     uint64_t* d_pieceClock = nullptr; size_t pieceClockCount = 0;    // option "piece_stats"
     struct Planning {                        // set by rts_ctx_plan_splits around its pieces-only launch
         const uint32_t* d_pieces; uint32_t nPieces, pieceRows; uint64_t* d_state; uint32_t* d_log; uint32_t logCap;
@@ -100,6 +104,7 @@ void clearSplits(rts_ctx* c) {
     rts_ctx::Splits& t = c->splits;
     if (t.d_skipMap) (void)hipFree(t.d_skipMap);
     if (t.d_pieces) (void)hipFree(t.d_pieces);
+    if (t.d_frontMap) (void)hipFree(t.d_frontMap);
     for (auto& e : t.state) if (e.second) (void)hipFree(e.second);
     t = rts_ctx::Splits();
 }
@@ -310,6 +315,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { c->useSplits = value ? 1 : 0; return RTS_OK; }     // 0: traces ignore an installed split table
+    if (!strcmp(key, "tune_for_motion")) { c->tuneForMotion = value ? 1 : 0; return RTS_OK; }   // rts_ctx_autotune: only tables that keep over a camera path
     if (!strcmp(key, "piece_stats")) {          // diagnostics: value = pieces to stamp (0 = off), see rts_ctx_read_piece_stats
         RTS_HIP(hipSetDevice(c->device));
         if (c->d_pieceClock) { RTS_HIP(hipFree(c->d_pieceClock)); c->d_pieceClock = nullptr; c->pieceClockCount = 0; }
@@ -361,6 +367,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "soft_split")) { *value = c->softSplit; return RTS_OK; }
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { *value = c->useSplits; return RTS_OK; }
+    if (!strcmp(key, "tune_for_motion")) { *value = c->tuneForMotion; return RTS_OK; }
     if (!strcmp(key, "split_tiles")) { *value = c->splits.valid ? (int)c->splits.nTiles : 0; return RTS_OK; }
     if (!strcmp(key, "front_tiles")) { *value = c->splits.valid ? (int)c->splits.nFront : 0; return RTS_OK; }
     if (!strcmp(key, "split_pieces")) { *value = c->splits.valid ? (int)c->splits.nPieces : 0; return RTS_OK; }
@@ -455,6 +462,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.waveStats = nullptr; p.waveRealtime = nullptr; p.clockProbe = nullptr; p.rowOrder = 0;
         p.skipMap = c->planning->d_pieces;   // (never read: no tile rows in this launch)
         p.pieces = c->planning->d_pieces; p.nPieces = c->planning->nPieces; p.pieceRows = c->planning->pieceRows;
+        p.frontMap = nullptr; p.frontStride = 0;                                 // (every record is a piece)
         p.tileState = c->planning->d_state; p.pieceLog = c->planning->d_log; p.pieceLogCap = c->planning->logCap;
         p.blocksY = 0;
         return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, 0));
@@ -469,6 +477,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.blocksY + sp.pieceRows <= 65535u) {
         if (uint64_t* st = splitState(c, stream)) {
             p.skipMap = sp.d_skipMap; p.pieces = sp.d_pieces; p.nPieces = sp.nPieces; p.pieceRows = sp.pieceRows;
+            p.frontMap = sp.d_frontMap; p.frontStride = sp.frontStride;
             p.tileState = st;
             p.allInTable = sp.allTiles ? 1u : 0u;
             if (c->d_pieceClock && c->pieceClockCount >= sp.nPieces) p.pieceClock = c->d_pieceClock;
@@ -762,7 +771,8 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
     if (tiles_out) *tiles_out = 0;
     if (pieces_out) *pieces_out = 0;
     if (!c || !k || !d_positions || !d_mask || !plan || !(plan->min_life_us > 0.f) || !(plan->piece_us > 0.f) || !(plan->end_after_us >= 0.f) ||
-        !(plan->front_life_us >= 0.f) || plan->front_life_us > plan->min_life_us || !(plan->front_share >= 0.f) || plan->front_share > 1.f)
+        !(plan->front_life_us >= 0.f) || plan->front_life_us > plan->min_life_us || !(plan->front_share >= 0.f) || plan->front_share > 1.f ||
+        plan->xcd_square > 65535u || plan->life_block > 65535u)
         return planRefused("arguments");
     if (light && light->nsamples > 1) return planRefused("more than one light sample");   // (soft shadows are dealt over waves by "soft_split")
     RTS_HIP(hipSetDevice(c->device));
@@ -805,6 +815,20 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
                 if (lives[nth] > frontLife) frontLife = lives[nth];
             }
         }
+        // life_block B: the front order knows the image only in blocks of B x B tiles -- a tile is as long as the longest tile of
+        // its block.  Coarser, so a little less gain on the frame it was measured on, but a camera that moves shifts what is long by
+        // whole tiles and leaves the blocks' order nearly as it was (profiles/r04/table_granularity.log).
+        const uint32_t B = plan->life_block > 1 ? plan->life_block : 1u;
+        std::unordered_map<uint32_t, float> blockLife;
+        if (B > 1)
+            for (size_t i = 0; i < waves; ++i) {
+                const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
+                if (r1 <= r0) continue;
+                const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
+                float& m = blockLife[(bx / B) | ((by / B) << 16)];
+                const float us = (float)(r1 - r0) * 0.01f;
+                if (us > m) m = us;
+            }
         for (size_t i = 0; i < waves; ++i) {
             const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
             if (r1 <= r0) continue;
@@ -813,7 +837,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             if (by >= blocksY) blocksY = by + 1;
             if (bx >= blocksX) continue;
             if (us > plan->min_life_us && (float)(r1 - began) * 0.01f > plan->end_after_us) sel.push_back({ us, bx | (by << 16) });
-            else if (frontLife > 0.f && us > frontLife) front.push_back({ us, bx | (by << 16) });
+            else if (frontLife > 0.f && us > frontLife) front.push_back({ B > 1 ? blockLife[(bx / B) | ((by / B) << 16)] : us, bx | (by << 16) });
         }
         if (sel.empty() && front.empty()) return RTS_OK;
         const auto longer = [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); };
@@ -843,6 +867,33 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             provisional[(size_t)t * 8 + 0] = sel[t].tile; provisional[(size_t)t * 8 + 1] = 0; provisional[(size_t)t * 8 + 2] = 0xFFFFFFFFu;
             provisional[(size_t)t * 8 + 3] = t | (1u << 24);                       // (dword 4: the walk starts at the root, offset 0)
         }
+        // xcd_square: the workgroups of a dispatch go round-robin over the 8 XCDs (record i runs on XCD i mod 8, each with an L2 of
+        // its own), so inside a band record i is taken from the tiles of "its" S x S-tile squares of the image: an XCD's L2 then
+        // holds the part of the tree its squares see instead of every XCD holding all of it.  (As a static placement of the plain
+        // launch this lost -- regions differ in cost and unbalance the XCDs, EXPERIMENTS.md --; inside a band of equal measured
+        // life every XCD gets the same number of equally long tiles.  profiles/r04/xcd_regions_in_table_order.log)
+        if (const uint32_t S = plan->xcd_square) {
+            std::vector<Sel> out; out.reserve(F);
+            for (size_t i = 0; i < F;) {
+                size_t j = i; const int b = band(front[i].us);
+                while (j < F && band(front[j].us) == b) ++j;
+                std::vector<Sel> bucket[8]; size_t head[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                for (size_t q = i; q < j; ++q) {
+                    const uint32_t rx = (front[q].tile & 0xFFFFu) / S, ry = (front[q].tile >> 16) / S;
+                    bucket[(rx + ry * 3u) & 7u].push_back(front[q]);            // (image order inside a bucket, as before)
+                }
+                for (size_t q = i; q < j; ++q) {
+                    uint32_t x = (uint32_t)(nPieces + q) & 7u;                  // the XCD this record will run on
+                    if (head[x] == bucket[x].size()) {                           // none of its own left: from the fullest bucket
+                        size_t most = 0;
+                        for (uint32_t y = 0; y < 8; ++y) if (bucket[y].size() - head[y] > most) { most = bucket[y].size() - head[y]; x = y; }
+                    }
+                    out.push_back(bucket[x][head[x]++]);
+                }
+                i = j;
+            }
+            front.swap(out);
+        }
         // the dispatch this table belongs to (what traceMaskImpl will compute for the same arguments)
         uint32_t rows = row_end - row_begin;
         if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
@@ -857,7 +908,11 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             if (t >= T) { frontRecords[(size_t)(t - T) * 8] = tile; frontRecords[(size_t)(t - T) * 8 + 2] = 0xFFFFFFFFu; }
         }
         // device side: planning walk of the selected tiles (one piece each, everything logged), then the quantiles
+        const uint32_t frontStride = (nPieces + F + 7u) / 8u;
+        std::vector<uint32_t> frontMap((size_t)frontStride * 8u, 0xFFFFFFFFu);   // (TraceParams::frontMap: record i at (i mod 8) * stride + i / 8)
+        for (uint32_t j = 0; j < F; ++j) { const uint32_t id = nPieces + j; frontMap[(size_t)(id & 7u) * frontStride + (id >> 3)] = front[j].tile; }
         void *d_cuts = nullptr, *d_first = nullptr, *d_prov = nullptr, *d_log = nullptr, *d_state = nullptr, *d_pieces = nullptr, *d_map = nullptr;
+        void* d_front = nullptr;
         const size_t logBytes = (size_t)T * (logCap + 1) * 4 + 16;
         hipError_t e = hipMalloc(&d_cuts, (size_t)T * 8 + 16);
         if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)T * 4 + 16);
@@ -867,6 +922,8 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         if (e == hipSuccess) e = hipMalloc(&d_pieces, (size_t)(nPieces + F) * 32 + 16);
         if (e == hipSuccess && F) e = hipMemcpy((char*)d_pieces + (size_t)nPieces * 32, frontRecords.data(), (size_t)F * 32, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&d_map, bitmap.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_front, frontMap.size() * 4 + 16);
+        if (e == hipSuccess) e = hipMemcpy(d_front, frontMap.data(), frontMap.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_cuts, cuts.data(), (size_t)T * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_first, first.data(), (size_t)T * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_prov, provisional.data(), (size_t)T * 32, hipMemcpyHostToDevice);
@@ -890,6 +947,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         if (status != RTS_OK || e != hipSuccess) {
             if (d_pieces) (void)hipFree(d_pieces);
             if (d_map) (void)hipFree(d_map);
+            if (d_front) (void)hipFree(d_front);
             (void)hipGetLastError();
             return status != RTS_OK ? status : hipStatus(e);
         }
@@ -898,6 +956,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         t.W = W; t.H = H; t.rowBegin = row_begin; t.rowEnd = row_end; t.bandRows = band_rows; t.nStripes = n_stripes; t.stripe = stripe;
         t.blocksX = blocksX; t.blocksY = keyBlocksY;
         t.d_skipMap = (uint32_t*)d_map; t.d_pieces = (uint32_t*)d_pieces;
+        t.d_frontMap = (uint32_t*)d_front; t.frontStride = frontStride;
         t.nPieces = nPieces + F; t.pieceRows = (nPieces + F + blocksX - 1) / blocksX; t.nTiles = T; t.nFront = F;
         t.allTiles = (size_t)T + F == waves && waves == (size_t)blocksX * keyBlocksY;   // every tile has a record: no tile rows are launched
         t.plan = *plan; t.plan.prev_stats = nullptr; t.plan.prev_realtime = nullptr; t.plan.prev_waves = 0;
@@ -1002,6 +1061,8 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
                 static const float share[3] = { 0.03f, 1.f / 3.f, 1.f };
                 if (i < 6) {
                     plan.front_share = share[i % 3];
+                    if (i % 3 == 2) plan.xcd_square = 32;                       // (the whole dispatch in table order: XCD-local too)
+                    if (c->tuneForMotion) plan.life_block = 16;                  // (sorted by 128 x 128-pixel blocks: see rts_split_plan)
                     if (i < 3) {
                         plan.min_life_us = 0.25f * T < 20.f ? 20.f : 0.25f * T; plan.end_after_us = 0.5f * T;
                         plan.piece_us = 0.1f * T < 8.f ? 8.f : 0.1f * T;
@@ -1015,6 +1076,9 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
             // first).  The table with the best ratio is the candidate; it must gain 1 %.
             float bestRatio = 1e30f, tableMs = bestMs;
             for (int i = 0; i < trials; ++i) {
+                // (a camera path: pieces belong to the very tiles of one camera, and a front list that is a share of the tiles is a set
+                //  of tiles too -- only the whole dispatch in block order was measured to keep: profiles/r04/table_granularity.log)
+                if (c->tuneForMotion && i != 5) continue;
                 fill(i);
                 uint32_t tiles = 0;
                 status = planSplitsImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, &plan, &tiles, nullptr);

@@ -74,6 +74,13 @@ struct TraceParams {
     uint64_t* pieceClock;     // diagnostics ("piece_stats"): per piece {100 MHz clock at its start, at its end}, or NULL
     uint32_t nPieces, pieceLogCap;
     uint32_t allInTable;      // every tile of the dispatch has a record: the grid is the records alone (no tile rows at all)
+    uint32_t frontStride;     // ... records per XCD in frontMap
+    // One dword per record, what a record's wave reads first: bx | by << 16 of a FRONT tile, 0xFFFFFFFF for a piece (which then
+    // reads its 8 dwords).  Record i lives at (i mod 8) * frontStride + i / 8: the dispatcher deals workgroups round-robin over
+    // the 8 XCDs, so every XCD reads ONE contiguous run of dwords -- 32 records per 128-byte line of its own L2 -- instead of
+    // every eighth 32-byte record of an array all eight L2s have to pull in (a dependent miss in front of the texel request:
+    // a table in plain image order was 2-5 % slower than no table).  NULL (planning launches): every record is a piece.
+    const uint32_t* frontMap;
     float offsets[64][4];
 };
 

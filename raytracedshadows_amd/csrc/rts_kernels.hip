@@ -1385,9 +1385,11 @@ void shadowMaskPacketKernel(TraceParams p) {
         if (blockIdx.y < pieceRows) {                                 // the head of the grid: records of the split table
             const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x;
             if (id >= p.nPieces) return;
-            const u32x4 rec = *(ConstVec4Ptr)(uintptr_t)(uniform64(p.pieces) + (uint64_t)id * 32u);
-            if (rec.w >> 24) { runPiece<BANDS>(p, lds); return; }     // a piece of a split tile: a path of its own
-            bx = rec.x & 0xFFFFu; by = rec.x >> 16;                   // a FRONT tile: a long tile's own wave, started first
+            const uint64_t mapFront = uniform64(p.frontMap);
+            const uint32_t slot = (id & 7u) * p.frontStride + (id >> 3);       // (this XCD's run of the map: TraceParams::frontMap)
+            const uint32_t tile = mapFront ? *(ConstU32Ptr)(uintptr_t)(mapFront + (uint64_t)slot * 4u) : 0xFFFFFFFFu;
+            if (tile == 0xFFFFFFFFu) { runPiece<BANDS>(p, lds); return; }     // a piece of a split tile: a path of its own
+            bx = tile & 0xFFFFu; by = tile >> 16;                     // a FRONT tile: a long tile's own wave, started first
         } else {
             const uint32_t k = blockIdx.y - pieceRows;
             by = rowOrder == 1u ? blocksY - 1u - k : (rowOrder == 2u ? ((k & 1u) ? (blocksY >> 1) - ((k + 1u) >> 1) : (blocksY >> 1) + (k >> 1)) : k);

@@ -79,7 +79,7 @@ with api.ShadowContext(0) as ctx:
                             plan = dict(min_life_us=float(rs.choice([2.0, 8.0, 30.0, 1e9])),
                                         piece_us=float(rs.choice([1.0, 4.0, 12.0])), max_pieces=int(rs.choice([2, 4, 8, 16])),
                                         end_after_us=float(rs.choice([0.0, 0.0, 20.0])), front_share=float(rs.choice([0.0, 0.03, 0.33, 1.0])),
-                                        front_life_us=0.0, max_tiles=int(rs.choice([0, 64, 8192])))
+                                        front_life_us=0.0, max_tiles=int(rs.choice([0, 64, 8192])), xcd_square=int(rs.choice([0, 0, 3, 32])), life_block=int(rs.choice([0, 0, 2, 16])))
                             try:
                                 ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, stripes=stripes, **plan)
                             except Exception:

@@ -80,7 +80,7 @@ for cfg in sys.argv[1:] or ["atrium_1080p"]:
                 t0 = time.perf_counter()
                 tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_m, light=wl.light, min_life_us=life, piece_us=piece, max_pieces=int(maxp),
                                                 end_after_us=endfrac * med * 1e3, front_life_us=front, front_share=share, stripes=STRIPE,
-                                                max_tiles=int(os.environ.get("MAXTILES", 0)))
+                                                max_tiles=int(os.environ.get("MAXTILES", 0)), xcd_square=int(os.environ.get("XCD_SQUARE", 0)))
                 plan_ms = (time.perf_counter() - t0) * 1e3
                 bad = check()
                 med2, mn2, b2b2 = timeit(ctx, go, N)

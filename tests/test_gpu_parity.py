@@ -530,11 +530,15 @@ def test_split_tables_never_change_the_mask(ctx):
         for kernel in (3, 8):
             ctx.set_option("kernel", kernel)
             # (life, piece, max pieces, ended after, front tiles: lived longer than / the longest share)
-            for life, piece, maxp, end, front, share in ((40.0, 10.0, 8, 0.0, 0.0, 0.0), (10.0, 3.0, 16, 0.0, 0.0, 0.0), (3.0, 1.0, 4, 0.0, 0.0, 0.0),
-                                                         (30.0, 8.0, 8, 0.0, 6.0, 0.0), (1e9, 1e9, 8, 0.0, 0.0, 0.5), (25.0, 8.0, 8, 20.0, 0.0, 1.0),
-                                                         (15.0, 5.0, 8, 40.0, 0.0, 0.0)):
+            # (the last number: xcd_square -- the front order dealt over the XCDs by image squares)
+            for life, piece, maxp, end, front, share, square in (
+                    (40.0, 10.0, 8, 0.0, 0.0, 0.0, 0), (10.0, 3.0, 16, 0.0, 0.0, 0.0, 0), (3.0, 1.0, 4, 0.0, 0.0, 0.0, 5),
+                    (30.0, 8.0, 8, 0.0, 6.0, 0.0, 0), (1e9, 1e9, 8, 0.0, 0.0, 0.5, 16), (25.0, 8.0, 8, 20.0, 0.0, 1.0, 0),
+                    (1e9, 1e9, 8, 0.0, 0.0, 1.0, 32), (25.0, 8.0, 8, 20.0, 0.0, 1.0, 1), (15.0, 5.0, 8, 40.0, 0.0, 0.0, 0)):
                 tiles, records = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=life, piece_us=piece,
-                                                 max_pieces=maxp, end_after_us=end, front_life_us=front, front_share=share)
+                                                 max_pieces=maxp, end_after_us=end, front_life_us=front, front_share=share, xcd_square=square,
+                                                 life_block=square // 2)
+                assert ctx.split_plan()["xcd_square"] == square and ctx.split_plan()["life_block"] == square // 2
                 split, fronts = ctx.get_option("split_tiles"), ctx.get_option("front_tiles")
                 assert split + fronts == tiles and ctx.get_option("split_pieces") == records and records >= 2 * split + fronts
                 assert (fronts > 100) == (front > 0 or share > 0 or split == 4096), (life, front, share, split, fronts)
@@ -1119,7 +1123,8 @@ def test_randomised_scenes_cameras_and_options(ctx, seed):
                     ctx.h2d(d_pos, pos)
                     tiles, _ = ctx.plan_splits(k, d_pos, W, H, d_mask, light=light, min_life_us=float(rs.choice([0.3, 1.0, 3.0])),
                                                piece_us=float(rs.choice([0.2, 1.0])), max_pieces=int(rs.choice([2, 5, 16])),
-                                               front_share=float(rs.choice([0.0, 0.4, 1.0])))
+                                               front_share=float(rs.choice([0.0, 0.4, 1.0])), xcd_square=int(rs.choice([0, 2, 32])),
+                                               life_block=int(rs.choice([0, 3, 16])))
                     got = np.full((H, W), 9, np.uint8)
                     ctx.h2d(d_mask, got)
                     ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)

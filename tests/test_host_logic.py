@@ -236,9 +236,10 @@ def test_headline_fraction_is_the_useful_share_and_split_plans_round_trip_as_tex
     assert bench.headline_fraction(dict(hbm), 0.8)["frac"] == 0.16                 # another bound: untouched
     assert bench.headline_fraction(dict(roof), None)["frac"] == 0.62
     plan = {"min_life_us": 20.25, "end_after_us": 67.5, "piece_us": 10.125, "front_life_us": 0.0, "front_share": 0.3125, "max_pieces": 8,
-            "max_tiles": 8192, "split_tiles": 5, "pieces": 20, "front_tiles": 700}
+            "max_tiles": 8192, "xcd_square": 32, "life_block": 16, "split_tiles": 5, "pieces": 20, "front_tiles": 700}
     text = bench.splits_arg(plan)
     back = bench.parse_splits(text)
     assert back == {"min_life_us": 20.25, "end_after_us": 67.5, "piece_us": 10.125, "front_life_us": 0.0, "front_share": 0.3125,
-                    "max_pieces": 8, "max_tiles": 8192}
+                    "max_pieces": 8, "max_tiles": 8192, "xcd_square": 32, "life_block": 16}
+    assert bench.parse_splits("20.25:67.5:10.125:0.0:0.3125:8:8192")["xcd_square"] == 0      # (text of an earlier round's run)
     assert bench.splits_arg(None) == "" and bench.parse_splits("") is None

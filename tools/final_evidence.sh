@@ -41,6 +41,8 @@ for CFG in city_4k courtyard_4k; do
 # split tables: the pieces' lives against the tiles' own waves; the tuner's choice on a moved camera / light; kernel stats of the table launch
 timeout -k 10 200 python tools/piece_stats.py --config atrium_1080p --kernel 3 --life 33 --end 0.5 --piece 13 --front 0 2>&1 | grep -v "^   " > $OUT/piece_stats_atrium_1080p.log
 timeout -k 10 900 python tools/tuning_robustness.py atrium_1080p city_4k courtyard_4k > $OUT/tuning_robustness.log 2>&1; grep -c reuse $OUT/tuning_robustness.log
+# ... and by the granularity of the lives a whole-dispatch table is sorted by (per tile / per block of tiles / not at all), with and without XCD squares
+timeout -k 10 400 python tools/table_granularity.py courtyard_4k city_4k 2>&1 | grep "^\[" > $OUT/table_granularity.log; KERNEL=3 timeout -k 10 200 python tools/table_granularity.py atrium_1080p 2>&1 | grep "^\[" >> $OUT/table_granularity.log; wc -l $OUT/table_granularity.log
 ASPLITS=$(python -c "import json,sys; sys.path.insert(0,'$REPO'); import bench; t=json.load(open('$OUT/bench_atrium_1080p.json'))['config'].get('split_table'); print(bench.splits_arg(t['plan']) if t else '')")
 AOPT=$(python -c "import json; print(json.load(open('$OUT/bench_atrium_1080p.json'))['config'].get('launch_options', ''))")
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_atrium -- python3 $REPO/bench.py --config atrium_1080p --kernel 3 --options "$AOPT" --splits "$ASPLITS" --no-secondary --no-pmc --no-probes --no-cpu-baseline > $OUT/trace_bench_atrium.json 2> $OUT/trace_bench_atrium.err); echo "trace atrium rc=$?"

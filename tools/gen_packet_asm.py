@@ -304,21 +304,28 @@ def loop_leaf(form):
           "v_subrev_f32 %[t5], s56, %[ox0]", "v_subrev_f32 %[t6], s57, %[oy0]", "v_subrev_f32 %[t7], s58, %[oz0]",   # dd = o - v0
           "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
           "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]", # b1 = dot(dd, s1) * invd
+          # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51).  A disjunction:
+          # once EVERY member is rejected by the conditions evaluated so far the rest of the test cannot change anything and
+          # is skipped (courtyard: every ray fails on b1 alone in 41 % of the wave-wide tests, before t in 69 %: tools/wide_sim.py)
+          "v_cmp_gt_f32 s[60:61], 0, %[t8]",
+          "v_cmp_lt_f32 s[62:63], 1.0, %[t8]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "s_andn2_b64 s[62:63], %[m0], s[60:61]",
+          "s_cbranch_scc0 13f",
           "v_mul_f32 %[t9], s42, %[t6]", "v_mul_f32 %[t10], s41, %[t7]", "v_sub_f32 %[t9], %[t9], %[t10]",     # s2.x = dd.y*e0.z - e0.y*dd.z
           "v_mul_f32 %[t10], s40, %[t7]", "v_mul_f32 %[t11], s42, %[t5]", "v_sub_f32 %[t10], %[t10], %[t11]",  # s2.y = dd.z*e0.x - e0.z*dd.x
           "v_mul_f32 %[t11], s41, %[t5]", "v_mul_f32 %[t12], s40, %[t6]", "v_sub_f32 %[t11], %[t11], %[t12]",  # s2.z = dd.x*e0.y - e0.x*dd.y
           "v_mul_f32 %[t12], %[dx0], %[t9]", "v_mul_f32 %[t13], %[dy0], %[t10]", "v_add_f32 %[t12], %[t12], %[t13]",
           "v_mul_f32 %[t13], %[dz0], %[t11]", "v_add_f32 %[t12], %[t12], %[t13]", "v_mul_f32 %[t12], %[t12], %[t4]",   # b2 = dot(d, s2) * invd
-          "v_mul_f32 %[t13], s44, %[t9]", "v_mul_f32 %[t14], s45, %[t10]", "v_add_f32 %[t13], %[t13], %[t14]",
-          "v_mul_f32 %[t14], s46, %[t11]", "v_add_f32 %[t13], %[t13], %[t14]", "v_mul_f32 %[t13], %[t13], %[t4]",     # t = dot(e1, s2) * invd
           "v_add_f32 %[t14], %[t8], %[t12]",                                                                            # b1 + b2
-          # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51)
-          "v_cmp_gt_f32 s[60:61], 0, %[t8]",
-          "v_cmp_lt_f32 s[62:63], 1.0, %[t8]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
           "v_cmp_gt_f32 s[62:63], 0, %[t12]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
           "v_cmp_lt_f32 s[62:63], 1.0, %[t14]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "s_andn2_b64 s[62:63], %[m0], s[60:61]",
+          "s_cbranch_scc0 13f",
+          "v_mul_f32 %[t13], s44, %[t9]", "v_mul_f32 %[t14], s45, %[t10]", "v_add_f32 %[t13], %[t13], %[t14]",
+          "v_mul_f32 %[t14], s46, %[t11]", "v_add_f32 %[t13], %[t13], %[t14]", "v_mul_f32 %[t13], %[t13], %[t4]",     # t = dot(e1, s2) * invd
           "v_cmp_gt_f32 s[62:63], 0, %[t13]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
           "v_cmp_lt_f32 s[62:63], %[tm0], %[t13]", "s_or_b64 s[60:61], s[60:61], s[62:63]",
+          "13:",
           "s_andn2_b64 s[62:63], %[m0], s[60:61]",         # members that hit the triangle: occluded, finished
           "s_or_b64 %[oc0], %[oc0], s[62:63]",
           "s_and_b64 s[60:61], %[m0], s[60:61]",           # members that missed: wait on the miss link

@@ -185,21 +185,27 @@ def triangle(dst, tag=0):
         f"v_subrev_f32 %[t5], {v0[0]}, %[ox]", f"v_subrev_f32 %[t6], {v0[1]}, %[oy]", f"v_subrev_f32 %[t7], {v0[2]}, %[oz]",   # dd = o - v0
         "v_mul_f32 %[t8], %[t5], %[t0]", "v_mul_f32 %[t9], %[t6], %[t1]", "v_add_f32 %[t8], %[t8], %[t9]",
         "v_mul_f32 %[t9], %[t7], %[t2]", "v_add_f32 %[t8], %[t8], %[t9]", "v_mul_f32 %[t8], %[t8], %[t4]",       # b1 = dot(dd, s1) * invd
+        # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51).  A disjunction: once
+        # EVERY lane of EXEC is rejected by the conditions evaluated so far, the rest of the test cannot change anything and is skipped
+        f"v_cmp_gt_f32 {dst}, 0, %[t8]",
+        f"v_cmp_lt_f32 {R2}, 1.0, %[t8]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"s_andn2_b64 {R2}, exec, {dst}",
+        f"s_cbranch_scc0 19{tag}f",
         f"v_mul_f32 %[t0], {e0[2]}, %[t6]", f"v_mul_f32 %[t3], {e0[1]}, %[t7]", "v_sub_f32 %[t0], %[t0], %[t3]",       # s2.x = dd.y*e0.z - e0.y*dd.z
         f"v_mul_f32 %[t1], {e0[0]}, %[t7]", f"v_mul_f32 %[t3], {e0[2]}, %[t5]", "v_sub_f32 %[t1], %[t1], %[t3]",       # s2.y = dd.z*e0.x - e0.z*dd.x
         f"v_mul_f32 %[t2], {e0[1]}, %[t5]", f"v_mul_f32 %[t3], {e0[0]}, %[t6]", "v_sub_f32 %[t2], %[t2], %[t3]",       # s2.z = dd.x*e0.y - e0.x*dd.y
         "v_mul_f32 %[t5], %[dx], %[t0]", "v_mul_f32 %[t6], %[dy], %[t1]", "v_add_f32 %[t5], %[t5], %[t6]",
         "v_mul_f32 %[t6], %[dz], %[t2]", "v_add_f32 %[t5], %[t5], %[t6]", "v_mul_f32 %[t5], %[t5], %[t4]",         # b2 = dot(d, s2) * invd
-        f"v_mul_f32 %[t6], {e1[0]}, %[t0]", f"v_mul_f32 %[t7], {e1[1]}, %[t1]", "v_add_f32 %[t6], %[t6], %[t7]",
-        f"v_mul_f32 %[t7], {e1[2]}, %[t2]", "v_add_f32 %[t6], %[t6], %[t7]", "v_mul_f32 %[t6], %[t6], %[t4]",       # t = dot(e1, s2) * invd
         "v_add_f32 %[t7], %[t8], %[t5]",                                                                             # b1 + b2
-        # reject = b1<0 || b1>1 || b2<0 || b1+b2>1 || t<0 || t>tmax   (ordered compares: false on NaN, comp:51)
-        f"v_cmp_gt_f32 {dst}, 0, %[t8]",
-        f"v_cmp_lt_f32 {R2}, 1.0, %[t8]", f"s_or_b64 {dst}, {dst}, {R2}",
         f"v_cmp_gt_f32 {R2}, 0, %[t5]", f"s_or_b64 {dst}, {dst}, {R2}",
         f"v_cmp_lt_f32 {R2}, 1.0, %[t7]", f"s_or_b64 {dst}, {dst}, {R2}",
+        f"s_andn2_b64 {R2}, exec, {dst}",
+        f"s_cbranch_scc0 19{tag}f",
+        f"v_mul_f32 %[t6], {e1[0]}, %[t0]", f"v_mul_f32 %[t7], {e1[1]}, %[t1]", "v_add_f32 %[t6], %[t6], %[t7]",
+        f"v_mul_f32 %[t7], {e1[2]}, %[t2]", "v_add_f32 %[t6], %[t6], %[t7]", "v_mul_f32 %[t6], %[t6], %[t4]",       # t = dot(e1, s2) * invd
         f"v_cmp_gt_f32 {R2}, 0, %[t6]", f"s_or_b64 {dst}, {dst}, {R2}",
-        f"v_cmp_lt_f32 {R2}, %[tm], %[t6]", f"s_or_b64 {dst}, {dst}, {R2}"]          # (tmax is the same for every ray of a launch: an SGPR)
+        f"v_cmp_lt_f32 {R2}, %[tm], %[t6]", f"s_or_b64 {dst}, {dst}, {R2}",          # (tmax is the same for every ray of a launch: an SGPR)
+        f"19{tag}:"]
 
 
 def loop(octant):

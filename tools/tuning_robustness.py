@@ -78,6 +78,7 @@ def main():
             print(f"[{cfg}] camera A: default {default_a:.4f} ms, tuned {tuned_a:.4f} ms ({(tuned_a / default_a - 1) * 100:+.1f} %): {choice}", flush=True)
             steps = (("camera + 0.1 %", 0.001, False), ("camera + 0.3 %", 0.003, False), ("camera + 1 %", 0.01, False), ("camera + 5 %", 0.05, False),
                      ("light swung 90 degrees", 0.0, True))
+            seen = {}
             for name, adv, swing in steps:
                 k, pos, light = frame(adv, swing)
                 # (b) A's choice reused: the options, and the table as it stands (planned on A's frame: never re-measured)
@@ -87,7 +88,7 @@ def main():
                     ctx.set_option(key, v)
                 if plan:
                     ctx.plan_splits(kA, d_pos, W, H, d_mask, light=lightA, **{q: plan[q] for q in ("min_life_us", "end_after_us", "piece_us",
-                                    "front_life_us", "front_share", "max_pieces", "max_tiles")})
+                                    "front_life_us", "front_share", "max_pieces", "max_tiles", "xcd_square", "life_block")})
                 ctx.h2d(d_pos, pos)
                 stale = timed(k, light)
                 check(k, pos, light, name + ", A's choice reused")
@@ -101,6 +102,35 @@ def main():
                 kept = (default - stale) / gain if gain > 0.01 * default else float("nan")
                 print(f"[{cfg}] {name}: default {default:.4f} ms, A's choice reused {stale:.4f} ms, tuned afresh {fresh:.4f} ms ({fresh_choice}); "
                       f"reuse keeps {kept * 100:.0f} % of the fresh tuning's gain, loses {(stale / fresh - 1) * 100:+.1f} % against it", flush=True)
+                seen[name] = (default, fresh)
+            # the same path with the tuner told that the camera will move ("tune_for_motion": tables sorted by blocks of 16 x 16 tiles, no pieces)
+            ctx.h2d(d_pos, posA)
+            reset()
+            ctx.set_option("tune_for_motion", 1)
+            ctx.autotune(kA, d_pos, W, H, d_mask, light=lightA)
+            ctx.set_option("tune_for_motion", 0)
+            motion_a = timed(kA, lightA)
+            check(kA, posA, lightA, "camera A, tuned for motion")
+            print(f"[{cfg}] camera A, tuned for motion: default {default_a:.4f} ms, tuned {motion_a:.4f} ms ({(motion_a / default_a - 1) * 100:+.1f} %): {describe()}, "
+                  f"plan {ctx.split_plan()}", flush=True)
+            for name, adv, swing in steps:
+                k, pos, light = frame(adv, swing)
+                ctx.h2d(d_pos, pos)
+                stale = timed(k, light)
+                check(k, pos, light, name + ", A's motion-tuned choice reused")
+                # ... against the library default measured right beside it (the table switched off, the default options)
+                mine = {key: ctx.get_option(key) for key in ("kernel", "packet_share", "row_order")}
+                ctx.set_option("tile_splits", 0)
+                for key, v in (("kernel", -1), ("packet_share", 4), ("row_order", 0)):
+                    ctx.set_option(key, v)
+                default = timed(k, light)
+                for key, v in mine.items():
+                    ctx.set_option(key, v)
+                ctx.set_option("tile_splits", 1)
+                fresh_gain = 1.0 - seen[name][1] / seen[name][0]
+                print(f"[{cfg}] {name}: A's motion-tuned choice reused {stale:.4f} ms against the default beside it {default:.4f} ms: {(stale / default - 1) * 100:+.1f} % "
+                      f"({(motion_a / default_a - 1) * 100:+.1f} % on camera A; a fresh tuning of this frame: {-fresh_gain * 100:+.1f} %, "
+                      f"the reused motion table keeps {(1 - stale / default) / fresh_gain * 100 if fresh_gain > 0.01 else float('nan'):.0f} % of that)", flush=True)
             ctx.free(d_pos)
             ctx.free(d_mask)
 
