@@ -62,6 +62,14 @@ int rtsh_obj_load(const char* path, float* vertices, size_t vertex_capacity, uin
 /* The parser's number reader (objparser.cpp:62-131), exposed so tests can pin it. */
 float rtsh_obj_parse_float(const char* text, int* consumed);
 
+/* Host logic of rts_ctx_plan_splits, reachable without a device (tests): the order of a split table's front records for n tiles
+ * {life_us[i], tiles[i] = bx | by << 16} with front_share 1 and no splits -- half-octave bands of life, longest first, image order
+ * inside a band; life_block B > 1: a tile counts as long as the longest tile of its B x B block; xcd_square S > 0: inside a band,
+ * record first_record + r is taken from the tiles of XCD ((first_record + r) mod 8)'s S x S squares while it has any (include/rts.h,
+ * rts_split_plan).  order_out[r] = index of the tile that becomes record first_record + r. */
+int rtsh_split_front_order(const float* life_us, const uint32_t* tiles, size_t n, uint32_t first_record, uint32_t xcd_square,
+                           uint32_t life_block, uint32_t* order_out);
+
 #ifdef __cplusplus
 }
 #endif

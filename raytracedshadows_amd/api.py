@@ -153,6 +153,15 @@ _sig("rts_ctx_autotune", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
      C.POINTER(C.c_int), C.POINTER(C.c_float))
 
 
+def split_front_order(life_us, tiles, first_record=0, xcd_square=0, life_block=0):
+    """rtsh_split_front_order: the planner's front order (host logic, no device): indices of the tiles in record order."""
+    life = np.ascontiguousarray(life_us, np.float32)
+    t = np.ascontiguousarray(tiles, np.uint32)
+    out = np.zeros(t.size, np.uint32)
+    _check(_lib.rtsh_split_front_order(_ptr(life), _ptr(t), t.size, first_record, xcd_square, life_block, _ptr(out)), "rtsh_split_front_order")
+    return out
+
+
 class SplitPlan(C.Structure):
     """rts_split_plan (include/rts.h)."""
     _fields_ = [("min_life_us", C.c_float), ("end_after_us", C.c_float), ("piece_us", C.c_float), ("front_life_us", C.c_float), ("front_share", C.c_float), ("max_pieces", C.c_uint32), ("max_tiles", C.c_uint32),
@@ -164,6 +173,7 @@ _sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants),
 _sig("rts_ctx_plan_splits_stripes", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32,
      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rts_ctx_clear_splits", C.c_int, C.c_void_p)
+_sig("rtsh_split_front_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 _sig("rts_selftest_reciprocal", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_ctx_get_split_plan", C.c_int, C.c_void_p, C.POINTER(SplitPlan))
 _sig("rts_ctx_autotune_stripes", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,

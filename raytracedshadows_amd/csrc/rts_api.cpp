@@ -764,6 +764,88 @@ static int measureDispatch(rts_ctx* c, const rts_constants* k, const rts_light* 
     return hipStatus(e);
 }
 
+// ---- the order of a split table's front records: host logic, also reachable without a device (rtsh_split_front_order) --------
+struct SplitSel { float us; uint32_t tile; };     // a tile (bx | by << 16) and the life it is sorted by
+
+// half-octaves of life (0.5 / 1 / 2 / 4 bands per octave and the exact order measured: profiles/r04/table_order_bands.log -- 2 and 4 are level)
+static int lifeBand(float us) { return (int)std::floor(std::log2(us < 0.25f ? 0.25f : us) * 2.f); }
+
+// life_block B: the front order knows the image only in blocks of B x B tiles -- a tile is as long as the longest tile of its
+// block.  Coarser, so a little less gain on the frame it was measured on, but a camera that moves shifts what is long by whole
+// tiles and leaves the blocks' order nearly as it was (profiles/r04/table_granularity.log).
+static std::unordered_map<uint32_t, float> blockLives(const std::vector<SplitSel>& tiles, uint32_t B) {
+    std::unordered_map<uint32_t, float> longest;
+    for (const SplitSel& t : tiles) {
+        float& m = longest[((t.tile & 0xFFFFu) / B) | (((t.tile >> 16) / B) << 16)];
+        if (t.us > m) m = t.us;
+    }
+    return longest;
+}
+
+// front tiles: longest first in half-octaves of life, image order inside one (neighbouring tiles walk the same part of the
+// tree: started together they share the scalar cache and the L2 as in the plain launch)
+static void sortFront(std::vector<SplitSel>& front) {
+    std::sort(front.begin(), front.end(), [](const SplitSel& a, const SplitSel& b) {
+        const int ba = lifeBand(a.us), bb = lifeBand(b.us);
+        if (ba != bb) return ba > bb;
+        const uint32_t ka = ((a.tile >> 16) << 16) | (a.tile & 0xFFFFu), kb = ((b.tile >> 16) << 16) | (b.tile & 0xFFFFu);
+        return ka < kb;
+    });
+}
+
+// xcd_square: the workgroups of a dispatch go round-robin over the 8 XCDs (record i runs on XCD i mod 8, each with an L2 of its
+// own), so inside a band record i is taken from the tiles of "its" S x S-tile squares of the image: an XCD's L2 then holds the
+// part of the tree its squares see instead of every XCD holding all of it.  (As a static placement of the plain launch this
+// lost -- regions differ in cost and unbalance the XCDs, EXPERIMENTS.md --; inside a band of equal measured life every XCD gets
+// the same number of equally long tiles.  profiles/r04/xcd_regions_in_table_order.log)  Bands stay where they are, and the
+// order inside a bucket stays the image order.
+static void dealOverXcds(std::vector<SplitSel>& front, uint32_t firstRecord, uint32_t S) {
+    const size_t F = front.size();
+    std::vector<SplitSel> out; out.reserve(F);
+    for (size_t i = 0; i < F;) {
+        size_t j = i; const int b = lifeBand(front[i].us);
+        while (j < F && lifeBand(front[j].us) == b) ++j;
+        std::vector<SplitSel> bucket[8]; size_t head[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (size_t q = i; q < j; ++q) {
+            const uint32_t rx = (front[q].tile & 0xFFFFu) / S, ry = (front[q].tile >> 16) / S;
+            bucket[(rx + ry * 3u) & 7u].push_back(front[q]);
+        }
+        for (size_t q = i; q < j; ++q) {
+            uint32_t x = (uint32_t)(firstRecord + q) & 7u;              // the XCD this record will run on
+            if (head[x] == bucket[x].size()) {                           // none of its own left: from the fullest bucket
+                size_t most = 0;
+                for (uint32_t y = 0; y < 8; ++y) if (bucket[y].size() - head[y] > most) { most = bucket[y].size() - head[y]; x = y; }
+            }
+            out.push_back(bucket[x][head[x]++]);
+        }
+        i = j;
+    }
+    front.swap(out);
+}
+
+// Test hook (tests/test_host_logic.py): the front order of n tiles {life_us[i], tiles[i] = bx | by << 16} as rts_ctx_plan_splits
+// would build it with front_share 1 and no splits; order_out[r] = index of the tile that becomes record first_record + r.
+extern "C" int rtsh_split_front_order(const float* life_us, const uint32_t* tiles, size_t n, uint32_t first_record, uint32_t xcd_square,
+                                      uint32_t life_block, uint32_t* order_out) {
+    if ((n && (!life_us || !tiles || !order_out)) || xcd_square > 65535u || life_block > 65535u) return RTS_ERR_INVALID_ARG;
+    try {
+        std::vector<SplitSel> all(n);
+        std::unordered_map<uint32_t, uint32_t> index;
+        for (size_t i = 0; i < n; ++i) { all[i] = { life_us[i], tiles[i] }; index[tiles[i]] = (uint32_t)i; }
+        if (index.size() != n) return RTS_ERR_INVALID_ARG;                 // a tile twice
+        const uint32_t B = life_block > 1 ? life_block : 1u;
+        std::vector<SplitSel> front = all;
+        if (B > 1) {
+            const auto longest = blockLives(all, B);
+            for (SplitSel& t : front) t.us = longest.at(((t.tile & 0xFFFFu) / B) | (((t.tile >> 16) / B) << 16));
+        }
+        sortFront(front);
+        if (xcd_square) dealOverXcds(front, first_record, xcd_square);
+        for (size_t r = 0; r < n; ++r) order_out[r] = index[front[r].tile];
+    } catch (...) { return RTS_ERR_CAPACITY; }
+    return RTS_OK;
+}
+
 // Plans the split table for ONE dispatch geometry (see include/rts.h).  Synchronous, default stream.
 static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
                           uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
@@ -796,7 +878,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             waves = stats.size() / 4;
         }
         // the tiles whose wave lived longer than min_life_us, longest first
-        struct Sel { float us; uint32_t tile; };
+        using Sel = SplitSel;
         std::vector<Sel> sel, front;                                            // to be split / to be started first, unsplit
         const uint32_t blocksX = (W + 7) / 8;
         uint32_t blocksY = 0;
@@ -815,20 +897,18 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
                 if (lives[nth] > frontLife) frontLife = lives[nth];
             }
         }
-        // life_block B: the front order knows the image only in blocks of B x B tiles -- a tile is as long as the longest tile of
-        // its block.  Coarser, so a little less gain on the frame it was measured on, but a camera that moves shifts what is long by
-        // whole tiles and leaves the blocks' order nearly as it was (profiles/r04/table_granularity.log).
-        const uint32_t B = plan->life_block > 1 ? plan->life_block : 1u;
+        const uint32_t B = plan->life_block > 1 ? plan->life_block : 1u;       // (blockLives)
         std::unordered_map<uint32_t, float> blockLife;
-        if (B > 1)
+        if (B > 1) {
+            std::vector<SplitSel> all;
+            all.reserve(waves);
             for (size_t i = 0; i < waves; ++i) {
                 const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
                 if (r1 <= r0) continue;
-                const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
-                float& m = blockLife[(bx / B) | ((by / B) << 16)];
-                const float us = (float)(r1 - r0) * 0.01f;
-                if (us > m) m = us;
+                all.push_back({ (float)(r1 - r0) * 0.01f, (uint32_t)(stats[i * 4 + 3] >> 48) | (((uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu) << 16) });
             }
+            blockLife = blockLives(all, B);
+        }
         for (size_t i = 0; i < waves; ++i) {
             const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
             if (r1 <= r0) continue;
@@ -842,16 +922,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
         if (sel.empty() && front.empty()) return RTS_OK;
         const auto longer = [](const Sel& a, const Sel& b) { return a.us > b.us || (a.us == b.us && a.tile < b.tile); };
         std::sort(sel.begin(), sel.end(), longer);
-        // front tiles: longest first in half-octaves of life, image order inside one (neighbouring tiles walk the same part of
-        // the tree: started together they share the scalar cache and the L2 as in the plain launch)
-        // (0.5 / 1 / 2 / 4 bands per octave and the exact order measured: profiles/r04/table_order_bands.log -- 2 and 4 are level)
-        const auto band = [](float us) { return (int)std::floor(std::log2(us < 0.25f ? 0.25f : us) * 2.f); };
-        std::sort(front.begin(), front.end(), [&](const Sel& a, const Sel& b) {
-            const int ba = band(a.us), bb = band(b.us);
-            if (ba != bb) return ba > bb;
-            const uint32_t ka = ((a.tile >> 16) << 16) | (a.tile & 0xFFFFu), kb = ((b.tile >> 16) << 16) | (b.tile & 0xFFFFu);
-            return ka < kb;
-        });
+        sortFront(front);
         if (sel.size() > maxTiles) { front.insert(front.begin(), sel.begin() + maxTiles, sel.end()); sel.resize(maxTiles); }   // (what is not split starts first at least)
         if (front.size() > 262144) front.resize(262144);
         const uint32_t T = (uint32_t)sel.size(), F = (uint32_t)front.size();
@@ -867,33 +938,7 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
             provisional[(size_t)t * 8 + 0] = sel[t].tile; provisional[(size_t)t * 8 + 1] = 0; provisional[(size_t)t * 8 + 2] = 0xFFFFFFFFu;
             provisional[(size_t)t * 8 + 3] = t | (1u << 24);                       // (dword 4: the walk starts at the root, offset 0)
         }
-        // xcd_square: the workgroups of a dispatch go round-robin over the 8 XCDs (record i runs on XCD i mod 8, each with an L2 of
-        // its own), so inside a band record i is taken from the tiles of "its" S x S-tile squares of the image: an XCD's L2 then
-        // holds the part of the tree its squares see instead of every XCD holding all of it.  (As a static placement of the plain
-        // launch this lost -- regions differ in cost and unbalance the XCDs, EXPERIMENTS.md --; inside a band of equal measured
-        // life every XCD gets the same number of equally long tiles.  profiles/r04/xcd_regions_in_table_order.log)
-        if (const uint32_t S = plan->xcd_square) {
-            std::vector<Sel> out; out.reserve(F);
-            for (size_t i = 0; i < F;) {
-                size_t j = i; const int b = band(front[i].us);
-                while (j < F && band(front[j].us) == b) ++j;
-                std::vector<Sel> bucket[8]; size_t head[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                for (size_t q = i; q < j; ++q) {
-                    const uint32_t rx = (front[q].tile & 0xFFFFu) / S, ry = (front[q].tile >> 16) / S;
-                    bucket[(rx + ry * 3u) & 7u].push_back(front[q]);            // (image order inside a bucket, as before)
-                }
-                for (size_t q = i; q < j; ++q) {
-                    uint32_t x = (uint32_t)(nPieces + q) & 7u;                  // the XCD this record will run on
-                    if (head[x] == bucket[x].size()) {                           // none of its own left: from the fullest bucket
-                        size_t most = 0;
-                        for (uint32_t y = 0; y < 8; ++y) if (bucket[y].size() - head[y] > most) { most = bucket[y].size() - head[y]; x = y; }
-                    }
-                    out.push_back(bucket[x][head[x]++]);
-                }
-                i = j;
-            }
-            front.swap(out);
-        }
+        if (plan->xcd_square) dealOverXcds(front, nPieces, plan->xcd_square);
         // the dispatch this table belongs to (what traceMaskImpl will compute for the same arguments)
         uint32_t rows = row_end - row_begin;
         if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }

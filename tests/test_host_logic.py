@@ -243,3 +243,85 @@ def test_headline_fraction_is_the_useful_share_and_split_plans_round_trip_as_tex
                     "max_pieces": 8, "max_tiles": 8192, "xcd_square": 32, "life_block": 16}
     assert bench.parse_splits("20.25:67.5:10.125:0.0:0.3125:8:8192")["xcd_square"] == 0      # (text of an earlier round's run)
     assert bench.splits_arg(None) == "" and bench.parse_splits("") is None
+
+
+def _band(us):
+    import math
+    return math.floor(math.log2(max(us, 0.25)) * 2.0)
+
+
+def test_split_front_order_is_a_banded_permutation_in_image_order():
+    """Host logic of rts_ctx_plan_splits (rtsh_split_front_order): every tile exactly once; half-octave bands of measured life,
+    longest first; image order (row-major) inside a band."""
+    from raytracedshadows_amd import api
+    rs = np.random.RandomState(5)
+    bx, by = np.meshgrid(np.arange(61, dtype=np.uint32), np.arange(37, dtype=np.uint32))
+    tiles = (bx | (by << np.uint32(16))).reshape(-1)
+    life = np.exp(rs.normal(2.0, 1.0, tiles.size)).astype(np.float32)              # 0.3 .. 200 us
+    perm = rs.permutation(tiles.size)                                               # (handed in in any order)
+    order = api.split_front_order(life[perm], tiles[perm])
+    assert sorted(order.tolist()) == list(range(tiles.size))
+    t, l = tiles[perm][order], life[perm][order]
+    bands = [_band(float(v)) for v in l]
+    assert all(a >= b for a, b in zip(bands, bands[1:])) and len(set(bands)) > 8
+    key = ((t >> 16).astype(np.int64) << 16) | (t & 0xFFFF)
+    for b in set(bands):
+        k = key[[i for i, v in enumerate(bands) if v == b]]
+        assert (np.diff(k) > 0).all()
+    # nothing to order: empty input; the same tile twice is refused
+    assert api.split_front_order(np.zeros(0, np.float32), np.zeros(0, np.uint32)).size == 0
+    with pytest.raises(api.RtsError):
+        api.split_front_order(np.ones(2, np.float32), np.array([7, 7], np.uint32))
+
+
+def test_split_front_order_deals_image_squares_over_the_xcds():
+    """xcd_square S: record first_record + r runs on XCD (first_record + r) mod 8 and is taken from that XCD's S x S-tile squares
+    (square (rx, ry) belongs to XCD (rx + 3 ry) mod 8) while it has any left in the band; bands stay where they are and the order
+    inside one XCD's tiles of a band stays the image order."""
+    from raytracedshadows_amd import api
+    S, first = 8, 5
+    bx, by = np.meshgrid(np.arange(64, dtype=np.uint32), np.arange(64, dtype=np.uint32))
+    tiles = (bx | (by << np.uint32(16))).reshape(-1)
+    xcd_of = (((tiles & 0xFFFF) // S) + ((tiles >> 16) // S) * 3) & 7
+
+    # one band, every XCD owns the same number of tiles: every record is one of its XCD's
+    order = api.split_front_order(np.full(tiles.size, 10.0, np.float32), tiles, first_record=first, xcd_square=S)
+    assert sorted(order.tolist()) == list(range(tiles.size))
+    runs_on = (first + np.arange(tiles.size)) & 7
+    assert (xcd_of[order] == runs_on).all()
+    for x in range(8):                                           # image order inside an XCD's share
+        t = tiles[order][runs_on == x]
+        k = ((t >> 16).astype(np.int64) << 16) | (t & 0xFFFF)
+        assert (np.diff(k) > 0).all()
+
+    # random lives: same bands as without the squares (as multisets per position), most records on their own XCD
+    rs = np.random.RandomState(11)
+    life = np.exp(rs.normal(2.0, 0.8, tiles.size)).astype(np.float32)
+    plain = api.split_front_order(life, tiles)
+    dealt = api.split_front_order(life, tiles, first_record=first, xcd_square=S)
+    assert sorted(dealt.tolist()) == list(range(tiles.size))
+    assert [_band(float(v)) for v in life[plain]] == [_band(float(v)) for v in life[dealt]]
+    assert (xcd_of[dealt] == runs_on).mean() > 0.85
+
+
+def test_split_front_order_by_blocks_only_knows_blocks():
+    """life_block B: a tile is as long as the longest tile of its B x B block -- all tiles of a block land in one band, and the
+    order does not change when lives move around INSIDE blocks (what a small camera step does)."""
+    from raytracedshadows_amd import api
+    rs = np.random.RandomState(3)
+    B = 4
+    bx, by = np.meshgrid(np.arange(40, dtype=np.uint32), np.arange(24, dtype=np.uint32))
+    tiles = (bx | (by << np.uint32(16))).reshape(-1)
+    block = ((tiles & 0xFFFF) // B) + ((tiles >> 16) // B) * 1000
+    life = np.exp(rs.normal(2.0, 1.0, tiles.size)).astype(np.float32)
+    order = api.split_front_order(life, tiles, life_block=B, xcd_square=16)
+    assert sorted(order.tolist()) == list(range(tiles.size))
+    longest = {b: float(life[block == b].max()) for b in np.unique(block)}
+    bands = [_band(longest[int(b)]) for b in block[order]]
+    assert all(a >= b for a, b in zip(bands, bands[1:]))
+    shuffled = life.copy()
+    for b in np.unique(block):                                   # the same lives, dealt anew inside every block
+        idx = np.flatnonzero(block == b)
+        shuffled[idx] = life[idx][rs.permutation(idx.size)]
+    assert (api.split_front_order(shuffled, tiles, life_block=B, xcd_square=16) == order).all()
+    assert (api.split_front_order(shuffled, tiles, xcd_square=16) != api.split_front_order(life, tiles, xcd_square=16)).any()
