@@ -869,6 +869,41 @@ static void wideSlots(const u32* bvh, u32 n, u32 root, int d, std::vector<WSlot>
 }
 }
 
+// depth 4 (14 with the cheap test): up to four slots chosen GREEDILY -- starting from the two children, the inner slot with the
+// largest box surface is replaced by its two children until there are four slots (or only leaves): what a surface-area-driven
+// collapse of the private copy would look like, against the fixed "two levels down" of depth 2.  (An experiment's count.)
+static void wideSlotsGreedy(const u32* bvh, u32 n, std::vector<WSlot>& out, bool withRootBox) {
+    struct Cand { u32 node; u32 parent; bool leaf; float area; };
+    auto area = [&](u32 c) {
+        const u32* a = bvh + (size_t)c * 8;
+        const float dx = u2f(a[4]) - u2f(a[0]), dy = u2f(a[5]) - u2f(a[1]), dz = u2f(a[6]) - u2f(a[2]);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto kids = [&](u32 m, Cand* k) {
+        const u32 left = m + 1, right = bvh[(size_t)left * 8 + 7];
+        const u32 cc[2] = { left, right };
+        for (int i = 0; i < 2; ++i) {
+            const bool leaf = bvh[(size_t)cc[i] * 8 + 3] != kInvalid;
+            k[i] = Cand{ cc[i], m, leaf, leaf ? 0.f : area(cc[i]) };
+        }
+    };
+    std::vector<Cand> cur(2);
+    kids(n, cur.data());
+    while (cur.size() < 4) {
+        int best = -1;
+        for (size_t i = 0; i < cur.size(); ++i) if (!cur[i].leaf && (best < 0 || cur[i].area > cur[best].area)) best = (int)i;
+        if (best < 0) break;
+        Cand k[2];
+        kids(cur[best].node, k);
+        cur[best] = k[0];
+        cur.insert(cur.begin() + best + 1, k[1]);              // (stream order kept: left before right)
+    }
+    for (const Cand& c : cur) {
+        if (c.leaf) out.push_back(WSlot{ (c.parent == n && !withRootBox) ? kInvalid : c.parent, c.node, true });
+        else out.push_back(WSlot{ c.node, c.node, false });
+    }
+}
+
 // Optional per-tile output of the next orc_wide_packet_sim call (tile t = by * (W / 8) + bx): nodes entered, box tests,
 // member lanes summed over those tests.  NULL switches it off.
 static uint32_t* g_tileSteps = nullptr; static uint32_t* g_tileTests = nullptr; static uint32_t* g_tileLanes = nullptr;
@@ -981,7 +1016,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                 if (!m) continue;
                 ++mySteps;
                 slots.clear();
-                wideSlots(bvh, n, n, depth, slots, cheap);
+                if (depth == 4) wideSlotsGreedy(bvh, n, slots, cheap); else wideSlots(bvh, n, n, depth, slots, cheap);
                 const size_t base = stack.size();
                 u32 prevBox = kInvalid - 1;
                 uint64_t prevHit = 0;
