@@ -908,7 +908,8 @@ static void wideSlotsGreedy(const u32* bvh, u32 n, std::vector<WSlot>& out, bool
 // member lanes summed over those tests.  NULL switches it off.
 static uint32_t* g_tileSteps = nullptr; static uint32_t* g_tileTests = nullptr; static uint32_t* g_tileLanes = nullptr;
 // More counts of the last orc_wide_packet_sim call: [0] triangle-test ROUNDS if every ray tested its own next leaf slot of a node
-// in the same wave-wide test (per node: the largest number of leaf slots one ray has to test), [1] rays summed over those rounds.
+// in the same wave-wide test (per node: the largest number of leaf slots one ray has to test), [1] rays summed over those rounds,
+// [2] wave-wide triangle tests with at most 16 participating rays, [3] ... with at most 8.
 static uint64_t g_simExtra[4] = { 0, 0, 0, 0 };
 extern "C" void orc_wide_packet_sim_extra(uint64_t* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_simExtra[i]; }
 extern "C" void orc_wide_packet_sim_per_tile(uint32_t* steps, uint32_t* tests, uint32_t* lanes) {
@@ -929,7 +930,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
     uint64_t violations = 0, falsePos = 0;
     float rootLo[3] = { u2f(bvh[0]), u2f(bvh[1]), u2f(bvh[2]) }, rootHi[3] = { u2f(bvh[4]), u2f(bvh[5]), u2f(bvh[6]) };
     uint64_t tiles = 0, steps = 0, boxT = 0, boxLanes = 0, triT = 0, triLanes = 0, longest = 0, mism = 0, boxD = 0, sq = 0, unsafe = 0;
-    uint64_t allB1 = 0, allBary = 0, allMiss = 0, rounds = 0, roundLanes = 0;
+    uint64_t allB1 = 0, allBary = 0, allMiss = 0, rounds = 0, roundLanes = 0, tri16 = 0, tri8 = 0;
     const uint32_t tx = W / 8, ty = H / 8;
     std::vector<uint64_t> histAll(64, 0);
 #ifdef _OPENMP
@@ -940,7 +941,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
         std::vector<WSlot> slots;
         std::vector<std::pair<u32, uint64_t>> stack;
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4) reduction(+ : tiles, steps, boxT, boxLanes, triT, triLanes, mism, boxD, sq, unsafe, violations, falsePos, allB1, allBary, allMiss, rounds, roundLanes) reduction(max : longest)
+#pragma omp for schedule(dynamic, 4) reduction(+ : tiles, steps, boxT, boxLanes, triT, triLanes, mism, boxD, sq, unsafe, violations, falsePos, allB1, allBary, allMiss, rounds, roundLanes, tri16, tri8) reduction(max : longest)
 #endif
         for (int64_t t = 0; t < (int64_t)tx * ty; ++t) {
             const uint32_t bx = (uint32_t)(t % tx), by = (uint32_t)(t / tx);
@@ -1043,6 +1044,8 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                     if (s.leaf) {
                         ++triT; triLanes += __builtin_popcountll(h);
                         for (u32 l = 0; l < 64; ++l) if ((h >> l) & 1) ++perLane[l];
+                        if (__builtin_popcountll(h) <= 16) ++tri16;
+                        if (__builtin_popcountll(h) <= 8) ++tri8;
                         {
                             const u32* a = bvh + (size_t)s.ref * 8; const u32* tt = bvh + (size_t)a[3] * 4;
                             const V3 e0 = { u2f(a[0]), u2f(a[1]), u2f(a[2]) }, e1 = { u2f(a[4]), u2f(a[5]), u2f(a[6]) }, v0 = { u2f(tt[0]), u2f(tt[1]), u2f(tt[2]) };
@@ -1077,6 +1080,6 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
     out[0] = tiles; out[1] = steps; out[2] = boxT; out[3] = boxLanes; out[4] = triT; out[5] = triLanes; out[6] = longest;
     out[7] = mism; out[8] = boxD; out[9] = sq; out[10] = unsafe; out[11] = violations; out[12] = falsePos;
     out[13] = allB1; out[14] = allBary; out[15] = allMiss;
-    g_simExtra[0] = rounds; g_simExtra[1] = roundLanes;
+    g_simExtra[0] = rounds; g_simExtra[1] = roundLanes; g_simExtra[2] = tri16; g_simExtra[3] = tri8;
     if (hist) for (int i = 0; i < 64; ++i) hist[i] = histAll[i];
 }
