@@ -908,6 +908,45 @@ def test_autotune_leaves_legal_options_and_the_same_mask(ctx):
         ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
 
 
+def test_autotune_for_motion_keeps_only_the_block_sorted_table(ctx):
+    """Option "tune_for_motion": the tuner may keep ONE kind of table -- the whole dispatch in table order, sorted by blocks of
+    16 x 16 tiles, dealt over the XCDs by squares, no pieces -- or none.  The mask of the tuned frame, of the same table under a
+    moved camera and of a moved light is the oracle's."""
+    wl = workloads.prepare("atrium", 960, 540)
+    W, H, sc = wl.W, wl.H, wl.scene
+    ctx.set_bvh(wl.packed)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+        ctx.set_option("tune_for_motion", 1)
+        assert ctx.get_option("tune_for_motion") == 1
+        ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        plan = ctx.split_plan()
+        if plan is not None:
+            assert plan["life_block"] == 16 and plan["xcd_square"] == 32 and plan["front_share"] == 1.0
+            assert ctx.get_option("split_tiles") == 0 and ctx.get_option("front_tiles") == ((W + 7) // 8) * ((H + 7) // 8)
+        want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+        assert (_device_frame(ctx, wl, d_pos, d_mask) == want).all()
+        # the camera 2 % further along its view direction, the same table
+        eye2 = (sc.eye + (sc.target - sc.eye) * np.float32(0.02)).astype(np.float32)
+        pos2, _ = api.primary_positions(wl.packed, eye2, sc.target, sc.fovy, W, H)
+        k2 = api.RayTracingConstants.make(eye2, sc.light_direction, W, H)
+        want2, _, _ = oracle.shadow_mask(wl.packed, k2.as_array(), oracle.light_from_product(wl.light, k2), pos2, W, H)
+        ctx.h2d(d_pos, pos2)
+        got = np.full((H, W), 9, np.uint8)
+        ctx.h2d(d_mask, got)
+        ctx.trace_shadow_mask_device(k2, d_pos, W, H, d_mask, light=wl.light)
+        ctx.synchronize()
+        ctx.d2h(got, d_mask)
+        assert (got == want2).all(), int((got != want2).sum())
+    finally:
+        ctx.set_option("tune_for_motion", 0)
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+        ctx.free(d_pos); ctx.free(d_mask)
+
+
 def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
     """Light inside the room: ray directions of one tile straddle the sign planes (generic form 8).  A blob whose
     inner boxes have bboxMin > bboxMax on an axis (another producer) must switch the ordered test off."""
