@@ -925,6 +925,11 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
     // plane against a per-ray constant that carries the slack, see wideRaySetup below) and a triangle hit only counts
     // after the exact test of the leaf's parent box; out[11] = tests where the exact form hits and the cheap one does
     // not (must be 0), out[12] = cheap hits that the exact form rejects (wasted work, not an error).
+    // depth >= 100 (experiment's count): leaf tests are PARKED -- a ray remembers the leaf (one per ray) and walks on; when a ray
+    // that already holds one meets another, every parked test of the tile is made at once (a "flush": each ray its own triangle).
+    // g_simExtra[2] = flushes, [3] = rays summed over them (the counts of tests with <= 16 / <= 8 rays are not made then).
+    const bool park = depth >= 100;
+    if (park) depth -= 100;
     const bool cheap = depth >= 10;
     if (cheap) depth -= 10;
     uint64_t violations = 0, falsePos = 0;
@@ -977,6 +982,7 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                 if (anyHit(bvh, o[l], tm[l], d[l], nullptr, nullptr)) expect |= 1ull << l;
             }
             uint64_t occluded = 0, mySteps = 0;
+            uint64_t parkedMask = 0; u32 parkedRef[64], parkedBox[64];
             const uint64_t boxT0 = boxT, boxLanes0 = boxLanes;
             auto box = [&](u32 n, u32 l) {
                 const u32* a = bvh + (size_t)n * 8;
@@ -1041,6 +1047,18 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                         }
                     }
                     if (!h) continue;
+                    if (s.leaf && park) {
+                        const u32 parentBox = s.boxNode != kInvalid ? s.boxNode : n;
+                        if (h & parkedMask) {                                   // somebody already holds one: every parked test now
+                            ++tri16; tri8 += __builtin_popcountll(parkedMask);
+                            for (u32 l = 0; l < 64; ++l) if (((parkedMask >> l) & 1) && tri(parkedRef[l], l) && (!cheap || box(parkedBox[l], l))) occluded |= 1ull << l;
+                            parkedMask = 0;
+                            h &= ~occluded;
+                        }
+                        for (u32 l = 0; l < 64; ++l) if ((h >> l) & 1) { parkedRef[l] = s.ref; parkedBox[l] = parentBox; }
+                        parkedMask |= h;
+                        continue;
+                    }
                     if (s.leaf) {
                         ++triT; triLanes += __builtin_popcountll(h);
                         for (u32 l = 0; l < 64; ++l) if ((h >> l) & 1) ++perLane[l];
@@ -1066,6 +1084,10 @@ extern "C" void orc_wide_packet_sim(const uint32_t* packed, const float* constan
                 }
                 std::reverse(stack.begin() + base, stack.end());   // first slot on top: DFS order
                 { unsigned mx = 0; for (u32 l = 0; l < 64; ++l) { roundLanes += perLane[l]; if (perLane[l] > mx) mx = perLane[l]; } rounds += mx; }
+            }
+            if (parkedMask) {                                                   // the walk is over: what is still parked
+                ++tri16; tri8 += __builtin_popcountll(parkedMask);
+                for (u32 l = 0; l < 64; ++l) if (((parkedMask >> l) & 1) && tri(parkedRef[l], l) && (!cheap || box(parkedBox[l], l))) occluded |= 1ull << l;
             }
             mism += __builtin_popcountll((occluded ^ expect) & live);
             steps += mySteps; sq += mySteps * mySteps; if (mySteps > longest) longest = mySteps; ++tiles;
