@@ -174,6 +174,11 @@ int rts_ctx_set_bvh(rts_ctx* ctx, const rts_vec4u* packed, size_t count_vec4);
  *   "row_order"     order in which the tile rows of a frame are dispatched: 0 first to last (default), 1 last to first,
  *                   2 middle row outwards (the rows dispatched last are the kernel's tail; which order wins depends on
  *                   where the scene's long rays are: profiles/r02/row_order_sweep.log)
+ *   "tile_splits"   1 (default): traces use an installed split table (rts_ctx_plan_splits); 0: they ignore it
+ *   "tune_for_motion" 0 (default): rts_ctx_autotune picks the fastest table for THIS frame; 1: only a table that keeps over a
+ *                   camera path -- the whole dispatch in table order sorted by blocks of 16 x 16 tiles (rts_split_plan:
+ *                   life_block, xcd_square), no pieces, no front lists
+ *   "piece_stats"   diagnostics, see rts_ctx_read_piece_stats;  get only: "split_tiles", "front_tiles", "split_pieces"
  *   "lds_pad"       experiment: extra dynamic LDS bytes per one-wave packet workgroup (throttles occupancy; default 0)
  *   "wave_stats"    diagnostics, see rts_ctx_read_wave_stats
  *   "clock_probe"   diagnostics, see rts_ctx_read_clock_probe
