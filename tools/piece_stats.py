@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--options", default="")
     ap.add_argument("--stripe", default="", help="n:r = the dispatch of stripe r of an n-way interleaved partition (32-row bands) instead of the frame")
     ap.add_argument("--tiles", type=int, default=0, help="max_tiles of the plan (0 = the library's 4096)")
+    ap.add_argument("--share", type=float, default=0.0, help="front_share: the longest share of all tiles starts first (1 = the whole dispatch in table order)")
+    ap.add_argument("--xcd", type=int, default=0, help="xcd_square")
     ap.add_argument("--front", type=float, default=0.0, help="front_life_us: tiles that lived longer start first, unsplit")
     args = ap.parse_args()
     stripes = (32, int(args.stripe.split(":")[0]), int(args.stripe.split(":")[1])) if args.stripe else None
@@ -69,7 +71,8 @@ def main():
         print(f"[{args.config}] kernel {args.kernel}: plain frame {plain * 1e3:.1f} us; with wave statistics: last wave starts at {start.max():.1f} us, "
               f"last ends at {end.max():.1f} us; wave life mean {life.mean():.1f} p50 {np.percentile(life, 50):.1f} p99 {np.percentile(life, 99):.1f} max {life.max():.1f} us")
         tiles, pieces = ctx.plan_splits(wl.constants, d_pos, W, H, d_mask, light=wl.light, min_life_us=args.life, piece_us=args.piece,
-                                        max_pieces=args.max_pieces, end_after_us=args.end * plain * 1e3, stripes=stripes, max_tiles=args.tiles, front_life_us=args.front)
+                                        max_pieces=args.max_pieces, end_after_us=args.end * plain * 1e3, stripes=stripes, max_tiles=args.tiles, front_life_us=args.front,
+                                        front_share=args.share, xcd_square=args.xcd)
         if not pieces:
             print("no tiles selected")
             return
