@@ -35,19 +35,24 @@ def test_struct_layouts_match_the_header():
     assert api.BVHNode_dtype.itemsize == 32                      # BVHBuilder.h:8-20
 
 
-def test_split_plan_layout_is_what_the_compiler_lays_out(tmp_path):
-    """rts_split_plan as gcc lays it out from include/rts.h against the ctypes mirror the tests and bench.py pass to the library:
-    size and the offset of every field (a field added to one side only would shift the pointers at its end)."""
+def test_struct_layouts_are_what_the_compiler_lays_out(tmp_path):
+    """rts_constants, rts_light and rts_split_plan as gcc lays them out from include/rts.h against the ctypes mirrors the tests and
+    bench.py pass to the library: size and the offset of every field (a field added to one side only would shift what follows)."""
     import subprocess
-    fields = [name for name, _ in api.SplitPlan._fields_]
+    pairs = (("rts_constants", api.RayTracingConstants), ("rts_light", api.Light), ("rts_split_plan", api.SplitPlan))
+    body = ""
+    for cname, mirror in pairs:
+        body += f'  printf("%zu", sizeof({cname}));\n'
+        body += "".join(f'  printf(" %zu", offsetof({cname}, {f}));\n' for f, _ in mirror._fields_) + '  printf("\\n");\n'
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rts.h"\nint main(void) {\n  printf("%zu", sizeof(rts_split_plan));\n'
-                   + "".join(f'  printf(" %zu", offsetof(rts_split_plan, {f}));\n' for f in fields) + "  return 0;\n}\n")
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rts.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert got[0] == ctypes.sizeof(api.SplitPlan)
-    assert got[1:] == [getattr(api.SplitPlan, f).offset for f in fields], fields
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    for (cname, mirror), line in zip(pairs, lines):
+        got = [int(v) for v in line.split()]
+        assert got[0] == ctypes.sizeof(mirror), cname
+        assert got[1:] == [getattr(mirror, f).offset for f, _ in mirror._fields_], cname
 
 
 def test_product_never_links_the_oracle():
