@@ -345,6 +345,10 @@ def tune_child(args):
         plan = ctx.split_plan()                                 # the split table the third stage kept (None: the plain launch won)
         if plan:
             plan.update(table_size(ctx))
+        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_square") + ctx.get_option("tile_order_block"):
+            # (soft shadows: no table, but the same order as a tile order -- rts_ctx_plan_tile_order)
+            plan = {"tile_order": {"xcd_square": ctx.get_option("tile_order_square"), "life_block": ctx.get_option("tile_order_block")},
+                    "ordered_tiles": ctx.get_option("tile_order_tiles")}
         ctx.free(d_pos)
         ctx.free(d_mask)
     print(json.dumps({"kernel": chosen, "ms": ms, "options": tuned, "splits": plan}))
@@ -361,6 +365,8 @@ def splits_arg(plan):
     """A split plan (dict of rts_split_plan's numbers) as command-line text for the child processes; '' = no table."""
     if not plan:
         return ""
+    if plan.get("tile_order"):
+        return f"order:{int(plan['tile_order']['xcd_square'])}:{int(plan['tile_order']['life_block'])}"
     return (":".join(repr(float(plan.get(k, 0.0))) for k in ("min_life_us", "end_after_us", "piece_us", "front_life_us", "front_share"))
             + f":{int(plan['max_pieces'])}:{int(plan.get('max_tiles', 0))}:{int(plan.get('xcd_square', 0))}:{int(plan.get('life_block', 0))}")
 
@@ -369,6 +375,8 @@ def parse_splits(text):
     if not text:
         return None
     f = text.split(":")
+    if f[0] == "order":
+        return {"tile_order": {"xcd_square": int(f[1]), "life_block": int(f[2]) if len(f) > 2 else 0}}
     return {"min_life_us": float(f[0]), "end_after_us": float(f[1]), "piece_us": float(f[2]), "front_life_us": float(f[3]),
             "front_share": float(f[4]), "max_pieces": int(f[5]), "max_tiles": int(f[6]), "xcd_square": int(f[7]) if len(f) > 7 else 0, "life_block": int(f[8]) if len(f) > 8 else 0}
 
@@ -378,6 +386,10 @@ def apply_splits(ctx, plan, wl, d_pos, d_mask, stripes=None):
     plan = parse_splits(plan) if isinstance(plan, str) else plan
     if not plan:
         return None
+    if plan.get("tile_order"):                                   # soft shadows: the tile order instead of a table (2 measuring launches)
+        tiles = ctx.plan_tile_order(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, stripes=stripes,
+                                    xcd_square=plan["tile_order"]["xcd_square"], life_block=plan["tile_order"].get("life_block", 0))
+        return {"split_tiles": 0, "pieces": 0, "front_tiles": 0, "ordered_tiles": tiles} if tiles else None
     tiles, records = ctx.plan_splits(wl.constants, d_pos, wl.W, wl.H, d_mask, light=wl.light, min_life_us=plan["min_life_us"],
                                      end_after_us=plan["end_after_us"], piece_us=plan["piece_us"], max_pieces=plan["max_pieces"],
                                      front_life_us=plan.get("front_life_us", 0.0), front_share=plan.get("front_share", 0.0),
@@ -452,6 +464,7 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
         # the shader clock from a probed run of the same launch RIGHT AFTER the timed region (the probe -- one wave per tile row
         # stamping both clocks -- is not part of the launches that are timed)
         ctx.set_option("clock_probe", probe_rows)
+        ctx.set_option("tile_order", 0)                          # (the probe stamps tile rows of the 2-D grid: a planned tile order is set aside for it)
         try:
             for _ in range(max(10, min(steps, 50))):
                 step()
@@ -459,6 +472,7 @@ def measure(ctx, step, steps, warmup, prewarm_seconds, barrier=None, probe_rows=
             clock = ctx.clock_probe_mhz(probe_rows)
         finally:
             ctx.set_option("clock_probe", 0)
+            ctx.set_option("tile_order", 1)
     return {"wall": wall, "kernel_ms": float(events_ms), "median_ms": float(np.median(per_launch)),
             "prewarm_launches": prewarm_launches, "clock_mhz": clock}
 
@@ -495,7 +509,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="kernel variant id (-1 = what rts_ctx_autotune picks for the frame)")
     ap.add_argument("--options", default="", help="context options for the traced frame, key=value,... (with --kernel; else what "
                                                   "rts_ctx_autotune picks: packet_share, row_order)")
-    ap.add_argument("--splits", default="", help="split table for the traced frame, min_life_us:end_after_us:piece_us:front_life_us:front_share:max_pieces:max_tiles[:xcd_square[:life_block]] (with "
+    ap.add_argument("--splits", default="", help="split table for the traced frame, min_life_us:end_after_us:piece_us:front_life_us:front_share:max_pieces:max_tiles[:xcd_square[:life_block]], or order:xcd_square:life_block for a planned tile order (with "
                                                  "--kernel; else what rts_ctx_autotune keeps)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--prewarm-seconds", type=float, default=0.6)
@@ -621,6 +635,9 @@ def main():
         split_plan = ctx.split_plan()
         if split_plan:
             split_table = table_size(ctx)
+        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_square") + ctx.get_option("tile_order_block"):
+            split_plan = {"tile_order": {"xcd_square": ctx.get_option("tile_order_square"), "life_block": ctx.get_option("tile_order_block")}}
+            split_table = {"split_tiles": 0, "pieces": 0, "front_tiles": 0, "ordered_tiles": ctx.get_option("tile_order_tiles")}
     else:
         if kernel_id >= 0:
             ctx.set_option("kernel", kernel_id)

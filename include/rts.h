@@ -244,6 +244,17 @@ const char* rts_ctx_last_kernel_name(rts_ctx* ctx);
 /* Dispatch order of the image tiles for traces whose workgroup count equals `count`: workgroup i works on tile
  * order[i] (a permutation of 0..count-1; NULL or 0 restores the natural order).  Speed only. */
 int rts_ctx_set_tile_order(rts_ctx* ctx, const uint32_t* order, size_t count);
+/* ... planned from one measured launch of THIS dispatch (any light, any number of samples; stripes as in
+ * rts_trace_shadow_mask_stripes_device, n_stripes 1 = the whole frame): the order a whole-dispatch split table runs in -- half-
+ * octave bands of measured tile life, longest first, each band dealt over the 8 XCDs by xcd_square x xcd_square-tile image squares
+ * (0: not), a tile counted as long as the longest of its life_block x life_block block (0 / 1: itself) --, for the launches that
+ * carry no table: soft shadows (16 samples on the city - 5.6 %, on the courtyard - 6.3 %).  rts_ctx_autotune does this for
+ * dispatches of more than one sample and keeps it when it gains 1 %.  *tiles = tiles ordered (0: none -- not a dispatch of one
+ * 8x8 tile per workgroup).  Options: "tile_order" 0 makes traces ignore the installed order; get "tile_order_tiles",
+ * "tile_order_square", "tile_order_block".  Synchronous, default stream.  Speed only. */
+int rts_ctx_plan_tile_order(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
+                            uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                            uint32_t xcd_square, uint32_t life_block, uint32_t* tiles);
 /* Free and total device memory in bytes (hipMemGetInfo on the context's device); either pointer may be NULL. */
 int rts_device_mem_info(rts_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Diagnostics (tools/wave_stats.py): after rts_ctx_set_option(ctx, "wave_stats", n_waves) the packet

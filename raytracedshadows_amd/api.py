@@ -173,6 +173,8 @@ _sig("rts_ctx_plan_splits", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants),
 _sig("rts_ctx_plan_splits_stripes", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32,
      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(SplitPlan), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rts_ctx_clear_splits", C.c_int, C.c_void_p)
+_sig("rts_ctx_plan_tile_order", C.c_int, C.c_void_p, C.POINTER(RayTracingConstants), C.POINTER(Light), C.c_void_p, C.c_uint32, C.c_uint32,
+     C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32))
 _sig("rtsh_split_front_order", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 _sig("rts_selftest_reciprocal", C.c_int, C.c_void_p, C.c_void_p)
 _sig("rts_ctx_get_split_plan", C.c_int, C.c_void_p, C.POINTER(SplitPlan))
@@ -464,6 +466,15 @@ class ShadowContext:
             _check(_lib.rts_ctx_autotune(self._h, C.byref(constants), lp, C.c_void_p(d_positions), width, height,
                                          C.c_void_p(d_mask), C.byref(chosen), C.byref(ms)), "rts_ctx_autotune")
         return int(chosen.value), float(ms.value)
+
+    def plan_tile_order(self, constants, d_positions, width, height, d_mask, light=None, stripes=None, xcd_square=32, life_block=0):
+        """rts_ctx_plan_tile_order: measures this dispatch, installs the longest-first, XCD-dealt tile order; returns the tiles ordered."""
+        tiles = C.c_uint32(0)
+        band, n, r = stripes if stripes is not None else (0, 1, 0)
+        _check(_lib.rts_ctx_plan_tile_order(self._h, C.byref(constants), C.byref(light) if light is not None else None, C.c_void_p(d_positions),
+                                            width, height, band, n, r, C.c_void_p(d_mask), xcd_square, life_block, C.byref(tiles)),
+               "rts_ctx_plan_tile_order")
+        return int(tiles.value)
 
     def split_plan(self):
         """Parameters of the installed split table as a dict (None without a table): rts_ctx_get_split_plan."""

@@ -36,6 +36,8 @@ struct rts_ctx {
     int blockWaves = 1;
     int ldsPad = 0;              // experiment knob: dynamic LDS bytes per workgroup (throttles occupancy)
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
+    int useTileOrder = 1;                    // option "tile_order": 0 ignores an installed order
+    uint32_t tileOrderSquare = 0, tileOrderBlock = 0;   // what rts_ctx_plan_tile_order planned with (0, 0: the caller's own order or none)
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
@@ -315,6 +317,7 @@ int rts_ctx_set_option(rts_ctx* c, const char* key, int value) {
     if (!strcmp(key, "wide_lane")) { c->wideLane = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "soft_split")) { c->softSplit = value ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { c->useSplits = value ? 1 : 0; return RTS_OK; }     // 0: traces ignore an installed split table
+    if (!strcmp(key, "tile_order")) { c->useTileOrder = value ? 1 : 0; return RTS_OK; }            // 0: traces ignore an installed tile order
     if (!strcmp(key, "tune_for_motion")) { c->tuneForMotion = value ? 1 : 0; return RTS_OK; }   // rts_ctx_autotune: only tables that keep over a camera path
     if (!strcmp(key, "piece_stats")) {          // diagnostics: value = pieces to stamp (0 = off), see rts_ctx_read_piece_stats
         RTS_HIP(hipSetDevice(c->device));
@@ -368,6 +371,10 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "wide_nodes")) { *value = (int)c->wideCount; return RTS_OK; }
     if (!strcmp(key, "tile_splits")) { *value = c->useSplits; return RTS_OK; }
     if (!strcmp(key, "tune_for_motion")) { *value = c->tuneForMotion; return RTS_OK; }
+    if (!strcmp(key, "tile_order")) { *value = c->useTileOrder; return RTS_OK; }
+    if (!strcmp(key, "tile_order_tiles")) { *value = (int)c->tileOrderCount; return RTS_OK; }
+    if (!strcmp(key, "tile_order_square")) { *value = (int)c->tileOrderSquare; return RTS_OK; }
+    if (!strcmp(key, "tile_order_block")) { *value = (int)c->tileOrderBlock; return RTS_OK; }
     if (!strcmp(key, "split_tiles")) { *value = c->splits.valid ? (int)c->splits.nTiles : 0; return RTS_OK; }
     if (!strcmp(key, "front_tiles")) { *value = c->splits.valid ? (int)c->splits.nFront : 0; return RTS_OK; }
     if (!strcmp(key, "split_pieces")) { *value = c->splits.valid ? (int)c->splits.nPieces : 0; return RTS_OK; }
@@ -438,7 +445,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.waveStats = c->d_waveStats;
         p.waveRealtime = c->d_waveStats + c->waveStatsBytes / 8;
     }
-    if (c->d_tileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
+    if (c->d_tileOrder && c->useTileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     if (c->d_clockProbe && p.grid2d && p.blocksY <= c->clockProbeRows) p.clockProbe = c->d_clockProbe;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
@@ -704,6 +711,7 @@ int rts_ctx_set_tile_order(rts_ctx* c, const uint32_t* order, size_t count) {
     if (!c) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_tileOrder) { RTS_HIP(hipFree(c->d_tileOrder)); c->d_tileOrder = nullptr; c->tileOrderCount = 0; }
+    c->tileOrderSquare = 0; c->tileOrderBlock = 0;
     if (!order || count == 0) return RTS_OK;
     try {
         std::vector<uint8_t> seen(count, 0);
@@ -735,13 +743,14 @@ int rts_ctx_read_clock_probe(rts_ctx* c, uint64_t* out, size_t rows) {
 // instantiation without a table, the second one read back.  Used by the planner and, once per tuning call, by the tuner.
 static int measureDispatch(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
                            uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
-                           std::vector<uint64_t>& stats, std::vector<uint64_t>& rt) {
+                           std::vector<uint64_t>& stats, std::vector<uint64_t>& rt, uint32_t perTile = 1) {
     int status = RTS_OK;
     uint64_t* keep = c->d_waveStats; const size_t keepBytes = c->waveStatsBytes;
     c->d_waveStats = nullptr; c->waveStatsBytes = 0;
     uint32_t rows = row_end - row_begin;
     if (n_stripes > 1) { const uint32_t bands = (H + band_rows - 1) / band_rows; rows = ((bands - stripe + n_stripes - 1) / n_stripes) * band_rows; }
-    const size_t waves = (size_t)((W + 7) / 8) * ((rows + 7) / 8);
+    const size_t tiles = (size_t)((W + 7) / 8) * ((rows + 7) / 8);
+    const size_t waves = tiles * perTile;                             // (soft shadows, "soft_split": 4 waves per tile)
     hipError_t e = hipMalloc((void**)&c->d_waveStats, waves * 64);
     if (e == hipSuccess) e = hipMemset(c->d_waveStats, 0, waves * 64);
     if (e == hipSuccess) {
@@ -751,7 +760,7 @@ static int measureDispatch(rts_ctx* c, const rts_constants* k, const rts_light* 
             status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
         c->useSplits = use;
         if (status == RTS_OK) e = hipDeviceSynchronize();
-        if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != waves) status = planRefused("not a dispatch of 8x8 tiles");
+        if (status == RTS_OK && e == hipSuccess && (size_t)c->lastBlocksX * c->lastBlocksY != tiles) status = planRefused("not a dispatch of 8x8 tiles");
         if (status == RTS_OK && e == hipSuccess) {
             stats.resize(waves * 4); rt.resize(waves * 4);
             e = hipMemcpy(stats.data(), c->d_waveStats, waves * 32, hipMemcpyDeviceToHost);
@@ -1014,6 +1023,55 @@ static int planSplitsImpl(rts_ctx* c, const rts_constants* k, const rts_light* l
     return RTS_OK;
 }
 
+// rts_ctx_plan_tile_order: the dispatch order of a split table's whole-dispatch form for the launches that cannot carry a table --
+// soft shadows (several samples per pixel, 4 waves per tile).  Wave statistics of this dispatch, a tile as long as its longest wave,
+// the order of sortFront / dealOverXcds (bands of life, longest first, each band dealt over the XCDs by image squares), installed as
+// the context's tile order (rts_ctx_set_tile_order: workgroup i walks tile order[i]).
+static int planTileOrderImpl(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                             uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
+                             uint32_t xcd_square, uint32_t life_block, uint32_t* tiles_out) {
+    if (tiles_out) *tiles_out = 0;
+    if (!c || !k || !d_positions || !d_mask || xcd_square > 65535u || life_block > 65535u) return RTS_ERR_INVALID_ARG;
+    RTS_HIP(hipSetDevice(c->device));
+    int status = rts_ctx_set_tile_order(c, nullptr, 0);
+    if (status != RTS_OK) return status;
+    if (c->blockWaves != 1 || c->swizzle) return RTS_OK;                           // (one tile per workgroup only)
+    const uint32_t perTile = (light && light->nsamples > 1 && c->softSplit) ? 4u : 1u;
+    std::vector<uint64_t> stats, rt;
+    status = measureDispatch(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, stats, rt, perTile);
+    if (status == RTS_ERR_INVALID_ARG) return RTS_OK;                               // not a dispatch of 8x8 tiles: no order
+    if (status != RTS_OK) return status;
+    if (c->lastVariant != rts::V_PACKET && c->lastVariant != rts::V_WIDE) return RTS_OK;
+    try {
+        const uint32_t blocksX = c->lastBlocksX, nTiles = c->lastBlocksX * c->lastBlocksY;
+        std::vector<float> life(nTiles, 0.f);
+        for (size_t i = 0; i < stats.size() / 4; ++i) {
+            const uint64_t r0 = rt[i * 4], r1 = rt[i * 4 + 1];
+            if (r1 <= r0) continue;
+            const uint32_t bx = (uint32_t)(stats[i * 4 + 3] >> 48), by = (uint32_t)(stats[i * 4 + 3] >> 32) & 0xFFFFu;
+            if (bx >= blocksX || by >= c->lastBlocksY) continue;
+            const float us = (float)(r1 - r0) * 0.01f;
+            float& m = life[(size_t)by * blocksX + bx];
+            if (us > m) m = us;                                                     // a tile is as long as its longest wave
+        }
+        std::vector<SplitSel> front(nTiles);
+        for (uint32_t t = 0; t < nTiles; ++t) front[t] = { life[t] > 0.f ? life[t] : 0.25f, (t % blocksX) | ((t / blocksX) << 16) };
+        if (life_block > 1) {
+            const auto longest = blockLives(front, life_block);
+            for (SplitSel& f : front) f.us = longest.at(((f.tile & 0xFFFFu) / life_block) | (((f.tile >> 16) / life_block) << 16));
+        }
+        sortFront(front);
+        if (xcd_square) dealOverXcds(front, 0u, xcd_square);
+        std::vector<uint32_t> order(nTiles);
+        for (uint32_t i = 0; i < nTiles; ++i) order[i] = (front[i].tile >> 16) * blocksX + (front[i].tile & 0xFFFFu);
+        status = rts_ctx_set_tile_order(c, order.data(), order.size());
+        if (status != RTS_OK) return status;
+        c->tileOrderSquare = xcd_square; c->tileOrderBlock = life_block;
+        if (tiles_out) *tiles_out = nTiles;
+    } catch (...) { return RTS_ERR_CAPACITY; }
+    return RTS_OK;
+}
+
 // Picks the kernel for THIS dispatch by timing the candidates on it (what a renderer does once per scene and resolution):
 // the lane-per-ray walk with work sharing, the packet kernel, the wide packet kernel (when the stream has a private copy).
 // Then, for a packet kernel, two launch parameters that are worth 2-6 % on some frames and cost as much on others
@@ -1053,7 +1111,15 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
     //  are shorter, which is what a striped multi-GPU frame needs -- tools/stripe_scaling.py)
     const int candidates[3] = { rts::V_WIDE, rts::V_PACKET, rts::V_SHARE };
     const int before = c->variant, shareBefore = c->packetShare, orderBefore = c->rowOrder;
-    auto giveUp = [&]() { c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; clearSplits(c); return status; };
+    auto giveUp = [&]() {
+        c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; clearSplits(c);
+        if (c->tileOrderSquare || c->tileOrderBlock) (void)rts_ctx_set_tile_order(c, nullptr, 0);
+        return status;
+    };
+    if (c->tileOrderSquare || c->tileOrderBlock) {                                // (an order an earlier tuning planned: the candidates meet the plain dispatch)
+        status = rts_ctx_set_tile_order(c, nullptr, 0);
+        if (status != RTS_OK) return status;
+    }
     uint64_t pixels = (uint64_t)W * (row_end - row_begin);
     if (n_stripes > 1) pixels /= n_stripes;
     int best = before;
@@ -1155,12 +1221,45 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
                 if (status != RTS_OK) return giveUp();
             }
             }
+        } else if (light && light->nsamples > 1 && c->blockWaves == 1 && !c->swizzle && c->useTileOrder) {
+            // ... for soft shadows (no table: 4 waves per tile) the whole-dispatch order as a tile order: bands of measured life,
+            // longest first, dealt over the XCDs by image squares (city x 16 samples - 5.6 %, courtyard - 6.3 %:
+            // profiles/r04/soft_tile_order.log); sorted by blocks when the camera will move.  Timed beside the plain launch.
+            uint32_t tiles = 0;
+            status = planTileOrderImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, 32u,
+                                       c->tuneForMotion ? 16u : 0u, &tiles);
+            if (status != RTS_OK) return giveUp();
+            if (tiles) {
+                for (const auto t0 = std::chrono::steady_clock::now(); status == RTS_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20);) {
+                    status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
+                    if (hipStreamSynchronize(nullptr) != hipSuccess) status = RTS_ERR_HIP;
+                }
+                if (status != RTS_OK) return giveUp();
+                float ms, plainMs;
+                if (!median5(&ms)) return giveUp();
+                c->useTileOrder = 0;
+                const bool ok = median5(&plainMs);
+                c->useTileOrder = 1;
+                if (!ok) return giveUp();
+                if (getenv("RTS_TUNE_LOG"))
+                    fprintf(stderr, "rts tune: tile order (%u tiles): %.4f ms against %.4f plain beside it\n", tiles, ms, plainMs);
+                if (ms / plainMs < 0.99f) bestMs = ms;
+                else { status = rts_ctx_set_tile_order(c, nullptr, 0); if (status != RTS_OK) return giveUp(); }
+            }
         }
     }
 tuned:
     if (chosen) *chosen = best;
     if (ms_out) *ms_out = bestMs;
     return RTS_OK;
+}
+
+int rts_ctx_plan_tile_order(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W, uint32_t H,
+                            uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask, uint32_t xcd_square, uint32_t life_block,
+                            uint32_t* tiles) {
+    if (W == 0 || H == 0 || n_stripes == 0 || stripe >= n_stripes || (n_stripes > 1 && (band_rows == 0 || band_rows % 8 != 0))) return RTS_ERR_INVALID_ARG;
+    if (n_stripes == 1) return planTileOrderImpl(c, k, light, d_positions, W, H, 0, H, 0, 1, 0, d_mask, xcd_square, life_block, tiles);
+    return planTileOrderImpl(c, k, light, d_positions, W, H, 0, H, band_rows, n_stripes, stripe, d_mask, xcd_square, life_block, tiles);
 }
 
 int rts_ctx_autotune(rts_ctx* c, const rts_constants* k, const rts_light* light, const float* d_positions, uint32_t W,

@@ -64,6 +64,19 @@ with api.ShadowContext(0) as ctx:
                 ctx.d2h(got, d_mask)
                 bad = int((got != want).sum())
                 assert bad == 0, (cases, sc.name, producer, W, H, kernel, spp, n, bad)
+                # round 4: a dispatch of several samples once more in a planned tile order (rts_ctx_plan_tile_order)
+                if kernel in (3, 8) and spp > 1 and n == 1:
+                    ctx.set_option("block_waves", 1); ctx.set_option("xcd_swizzle", 0)
+                    ordered = ctx.plan_tile_order(k, d_pos, W, H, d_mask, light=light, xcd_square=int(rs.choice([0, 3, 32])), life_block=int(rs.choice([0, 2, 16])))
+                    got = np.full((H, W), 7, np.uint8)
+                    ctx.h2d(d_mask, got)
+                    ctx.trace_shadow_mask_device(k, d_pos, W, H, d_mask, light=light)
+                    ctx.synchronize()
+                    ctx.d2h(got, d_mask)
+                    ctx.set_tile_order(None)
+                    bad = int((got != want).sum())
+                    assert bad == 0, (cases, sc.name, producer, W, H, kernel, spp, "tile order", ordered, bad)
+                    tables += 1 if ordered else 0
                 # round 4: the same dispatch(es) through a split table with random thresholds, or the tuner's own choice
                 if kernel in (3, 8) and spp == 1 and ctx.get_option("wide_nodes") > 0:
                     ctx.set_option("block_waves", 1); ctx.set_option("wide_lane", 0); ctx.set_option("xcd_swizzle", 0)

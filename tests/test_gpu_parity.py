@@ -947,6 +947,63 @@ def test_autotune_for_motion_keeps_only_the_block_sorted_table(ctx):
         ctx.free(d_pos); ctx.free(d_mask)
 
 
+def test_planned_tile_order_never_changes_the_mask(ctx):
+    """rts_ctx_plan_tile_order: soft shadows (no split table: four waves per tile) dispatched longest tile first, dealt over the
+    XCDs by image squares.  The mask -- counts of unoccluded samples -- is the oracle's with the order on, off, sorted by blocks,
+    for one stripe of three, and after the tuner has had its say."""
+    wl = workloads.prepare("atrium", 640, 360)
+    W, H = wl.W, wl.H
+    light = api.Light.make(api.Light.POINT, wl.scene.light_point, scenes.jitter_offsets(16, 0.5, 3))
+    want, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(light, wl.constants), wl.positions, W, H)
+    tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    ctx.set_bvh(wl.packed)
+    d_pos, d_mask = ctx.malloc(wl.positions.nbytes), ctx.malloc(W * H)
+
+    def frame():
+        got = np.full((H, W), 99, np.uint8)
+        ctx.h2d(d_mask, got)
+        ctx.trace_shadow_mask_device(wl.constants, d_pos, W, H, d_mask, light=light)
+        ctx.synchronize()
+        ctx.d2h(got, d_mask)
+        return got
+
+    try:
+        ctx.h2d(d_pos, wl.positions)
+        for kernel in (3, 8):
+            ctx.set_option("kernel", kernel)
+            for square, block in ((32, 0), (0, 0), (5, 4)):
+                assert ctx.plan_tile_order(wl.constants, d_pos, W, H, d_mask, light=light, xcd_square=square, life_block=block) == tiles
+                assert ctx.get_option("tile_order_tiles") == tiles and ctx.get_option("tile_order_square") == square
+                assert (frame() == want).all(), (kernel, square, block)
+            ctx.set_option("tile_order", 0)
+            assert (frame() == want).all()
+            ctx.set_option("tile_order", 1)
+            # one stripe of three: an order for ITS dispatch; the full frame then runs without (another workgroup count)
+            assert ctx.plan_tile_order(wl.constants, d_pos, W, H, d_mask, light=light, stripes=(32, 3, 1)) > 0
+            got = np.full((H, W), 99, np.uint8)
+            ctx.h2d(d_mask, got)
+            ctx.trace_shadow_mask_stripes_device(wl.constants, d_pos, W, H, d_mask, 32, 3, 1, light=light)
+            ctx.synchronize()
+            ctx.d2h(got, d_mask)
+            own = np.zeros(H, bool)
+            for b, e in partition.stripe_rows(H, 3, 1, band=32, interleaved=True):
+                own[b:e] = True
+            assert (got[own] == want[own]).all() and (got[~own] == 99).all()
+            assert (frame() == want).all()
+        # the tuner: plans an order for a dispatch of several samples, keeps it or not; a one-sample frame gets none
+        ctx.set_option("kernel", -1)
+        ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=light)
+        assert ctx.get_option("tile_order_tiles") in (0, tiles)
+        assert (frame() == want).all()
+        ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light)
+        assert ctx.get_option("tile_order_tiles") == 0
+    finally:
+        ctx.set_tile_order(None)
+        ctx.clear_splits()
+        ctx.set_option("kernel", -1); ctx.set_option("packet_share", 4); ctx.set_option("row_order", 0)
+        ctx.free(d_pos); ctx.free(d_mask)
+
+
 def test_mixed_sign_and_unordered_boxes_take_the_generic_slab_test(ctx):
     """Light inside the room: ray directions of one tile straddle the sign planes (generic form 8).  A blob whose
     inner boxes have bboxMin > bboxMax on an axis (another producer) must switch the ordered test off."""

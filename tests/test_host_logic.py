@@ -325,3 +325,17 @@ def test_split_front_order_by_blocks_only_knows_blocks():
         shuffled[idx] = life[idx][rs.permutation(idx.size)]
     assert (api.split_front_order(shuffled, tiles, life_block=B, xcd_square=16) == order).all()
     assert (api.split_front_order(shuffled, tiles, xcd_square=16) != api.split_front_order(life, tiles, xcd_square=16)).any()
+
+
+def test_bench_carries_a_planned_tile_order_as_text():
+    """Soft shadows take no split table; what the tuner keeps for them -- a planned tile order -- travels from bench.py's tuning
+    child to its profiler children in the same text channel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = bench.splits_arg({"tile_order": {"xcd_square": 32, "life_block": 16}, "ordered_tiles": 129600})
+    assert text == "order:32:16" and bench.parse_splits(text) == {"tile_order": {"xcd_square": 32, "life_block": 16}}
+    assert bench.parse_splits("order:32") == {"tile_order": {"xcd_square": 32, "life_block": 0}}
