@@ -1225,24 +1225,39 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
             // ... for soft shadows (no table: 4 waves per tile) the whole-dispatch order as a tile order: bands of measured life,
             // longest first, dealt over the XCDs by image squares (city x 16 samples - 5.6 %, courtyard - 6.3 %:
             // profiles/r04/soft_tile_order.log); sorted by blocks when the camera will move.  Timed beside the plain launch.
-            uint32_t tiles = 0;
-            status = planTileOrderImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, 32u,
-                                       c->tuneForMotion ? 16u : 0u, &tiles);
-            if (status != RTS_OK) return giveUp();
-            if (tiles) {
+            // Both packet families are tried in their own order (the first stage chose between them in the plain order, where they
+            // are within 2 % on these frames; in order the stackless packet gains more: city x 16 samples 2.25 against 2.39 ms).
+            auto ordered = [&](int variant, float* ms, uint32_t* tiles) {
+                c->variant = variant;
+                status = planTileOrderImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, 32u,
+                                           c->tuneForMotion ? 16u : 0u, tiles);
+                if (status != RTS_OK) return false;
+                if (!*tiles) return true;
                 for (const auto t0 = std::chrono::steady_clock::now(); status == RTS_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20);) {
                     status = traceMaskImpl(c, k, light, d_positions, W, H, row_begin, row_end, band_rows, n_stripes, stripe, d_mask, nullptr);
                     if (hipStreamSynchronize(nullptr) != hipSuccess) status = RTS_ERR_HIP;
                 }
-                if (status != RTS_OK) return giveUp();
-                float ms, plainMs;
-                if (!median5(&ms)) return giveUp();
+                return status == RTS_OK && median5(ms);
+            };
+            const int other = best == rts::V_WIDE ? rts::V_PACKET : (c->wideCount ? rts::V_WIDE : -1);
+            uint32_t tiles = 0, tilesOther = 0;
+            float ms = 0.f, msOther = 1e30f;
+            if (other >= 0) { if (!ordered(other, &msOther, &tilesOther)) return giveUp(); if (!tilesOther) msOther = 1e30f; }
+            if (!ordered(best, &ms, &tiles)) return giveUp();                     // (last: its order is the one left installed)
+            if (tiles && msOther < ms * 0.98f) {                                   // the other family, in its order, is ahead: take it
+                best = other;
+                if (!ordered(best, &ms, &tiles)) return giveUp();
+            }
+            c->variant = best;
+            if (tiles) {
+                float plainMs;
                 c->useTileOrder = 0;
                 const bool ok = median5(&plainMs);
                 c->useTileOrder = 1;
                 if (!ok) return giveUp();
                 if (getenv("RTS_TUNE_LOG"))
-                    fprintf(stderr, "rts tune: tile order (%u tiles): %.4f ms against %.4f plain beside it\n", tiles, ms, plainMs);
+                    fprintf(stderr, "rts tune: tile order (%u tiles, kernel %d): %.4f ms against %.4f plain beside it (the other family in its order: %.4f)\n",
+                            tiles, best, ms, plainMs, msOther);
                 if (ms / plainMs < 0.99f) bestMs = ms;
                 else { status = rts_ctx_set_tile_order(c, nullptr, 0); if (status != RTS_OK) return giveUp(); }
             }
