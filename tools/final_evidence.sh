@@ -36,7 +36,7 @@ done
 for a in "city_4k 8" "courtyard_4k 8" "city_4k_soft16 3"; do set -- $a
   timeout -k 10 300 python tools/stripe_scaling.py --config $1 --kernel $2 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_$1_kernel$2.log; tail -1 $OUT/stripe_scaling_$1_kernel$2.log | cut -c1-60; done
 # ... and what rank r of `bench.py --gpus N` executes since round 4: every stripe tuned on its own dispatch (kernel, share, split table)
-for CFG in city_4k courtyard_4k; do
+for CFG in city_4k courtyard_4k city_4k_soft16; do
   timeout -k 10 400 python tools/stripe_scaling.py --config $CFG --tune-stripes 2>&1 | grep "stripe(s)" > $OUT/stripe_scaling_${CFG}_tuned_per_stripe.log; tail -1 $OUT/stripe_scaling_${CFG}_tuned_per_stripe.log | cut -c1-120; done
 # split tables: the pieces' lives against the tiles' own waves; the tuner's choice on a moved camera / light; kernel stats of the table launch
 timeout -k 10 200 python tools/piece_stats.py --config atrium_1080p --kernel 3 --life 33 --end 0.5 --piece 13 --front 0 2>&1 | grep -v "^   " > $OUT/piece_stats_atrium_1080p.log

@@ -50,7 +50,8 @@ def main():
                 if args.tune_stripes:
                     ctx.set_option("packet_share", 4)
                     kid, _ = ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=wl.light, stripes=(args.band, n, r))
-                    tuned.append(f"k{kid}/s{ctx.get_option('packet_share')}/{ctx.get_option('split_tiles')}t")
+                    tuned.append(f"k{kid}/s{ctx.get_option('packet_share')}/{ctx.get_option('split_tiles')}t"
+                                 + ("/ordered" if ctx.get_option("tile_order_tiles") else ""))
                     for _ in range(100):
                         go()
                 ts = []
@@ -62,7 +63,7 @@ def main():
             base = base or worst
             print(f"[{args.config}] band {args.band}, {n} stripe(s): per-stripe ms {' '.join(f'{t:.4f}' for t in times)}; slowest {worst:.4f} ms "
                   f"-> {wl.rays / worst / 1e6:.1f} Grays/s aggregate, predicted efficiency {base / (n * worst) * 100:.0f} % ({ctx.last_kernel_name()})"
-                  + (f" tuned per stripe (kernel/share/split tiles): {' '.join(tuned)}" if tuned else ""), flush=True)
+                  + (f" tuned per stripe (kernel/share/split tiles[/ordered = a planned tile order]): {' '.join(tuned)}" if tuned else ""), flush=True)
         ctx.free(d_pos)
         ctx.free(d_mask)
 
