@@ -345,7 +345,7 @@ def tune_child(args):
         plan = ctx.split_plan()                                 # the split table the third stage kept (None: the plain launch won)
         if plan:
             plan.update(table_size(ctx))
-        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_square") + ctx.get_option("tile_order_block"):
+        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_planned"):
             # (soft shadows: no table, but the same order as a tile order -- rts_ctx_plan_tile_order)
             plan = {"tile_order": {"xcd_square": ctx.get_option("tile_order_square"), "life_block": ctx.get_option("tile_order_block")},
                     "ordered_tiles": ctx.get_option("tile_order_tiles")}
@@ -635,7 +635,7 @@ def main():
         split_plan = ctx.split_plan()
         if split_plan:
             split_table = table_size(ctx)
-        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_square") + ctx.get_option("tile_order_block"):
+        elif ctx.get_option("tile_order_tiles") and ctx.get_option("tile_order_planned"):
             split_plan = {"tile_order": {"xcd_square": ctx.get_option("tile_order_square"), "life_block": ctx.get_option("tile_order_block")}}
             split_table = {"split_tiles": 0, "pieces": 0, "front_tiles": 0, "ordered_tiles": ctx.get_option("tile_order_tiles")}
     else:

@@ -250,8 +250,10 @@ int rts_ctx_set_tile_order(rts_ctx* ctx, const uint32_t* order, size_t count);
  * (0: not), a tile counted as long as the longest of its life_block x life_block block (0 / 1: itself) --, for the launches that
  * carry no table: soft shadows (16 samples on the city - 5.6 %, on the courtyard - 6.3 %).  rts_ctx_autotune does this for
  * dispatches of more than one sample and keeps it when it gains 1 %.  *tiles = tiles ordered (0: none -- not a dispatch of one
- * 8x8 tile per workgroup).  Options: "tile_order" 0 makes traces ignore the installed order; get "tile_order_tiles",
- * "tile_order_square", "tile_order_block".  Synchronous, default stream.  Speed only. */
+ * 8x8 tile per workgroup).  An order planned on a dispatch of several samples is used by such dispatches only: one-sample traces
+ * of the same size keep their everyday launch (and their split table).  Options: "tile_order" 0 makes traces ignore the
+ * installed order; get "tile_order_tiles", "tile_order_planned", "tile_order_square", "tile_order_block".  Synchronous, default
+ * stream.  Speed only. */
 int rts_ctx_plan_tile_order(rts_ctx* ctx, const rts_constants* constants, const rts_light* light, const float* d_positions,
                             uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_stripes, uint32_t stripe, uint8_t* d_mask,
                             uint32_t xcd_square, uint32_t life_block, uint32_t* tiles);

@@ -38,6 +38,8 @@ struct rts_ctx {
     uint32_t* d_tileOrder = nullptr; size_t tileOrderCount = 0;
     int useTileOrder = 1;                    // option "tile_order": 0 ignores an installed order
     uint32_t tileOrderSquare = 0, tileOrderBlock = 0;   // what rts_ctx_plan_tile_order planned with (0, 0: the caller's own order or none)
+    bool tileOrderPlanned = false;           // installed by rts_ctx_plan_tile_order (the tuner may replace it), not by the caller
+    bool tileOrderSoftOnly = false;          // planned on a dispatch of several samples: one-sample dispatches of the same size keep their everyday launch
     uint64_t* d_waveStats = nullptr; size_t waveStatsBytes = 0; size_t waveStatsUsed = 0;
     uint64_t launches = 0;
     int rowOrder = 0;                  // dispatch order of tile rows on 2-D grids: 0 top-down, 1 bottom-up, 2 middle-out
@@ -373,6 +375,7 @@ int rts_ctx_get_option(rts_ctx* c, const char* key, int* value) {
     if (!strcmp(key, "tune_for_motion")) { *value = c->tuneForMotion; return RTS_OK; }
     if (!strcmp(key, "tile_order")) { *value = c->useTileOrder; return RTS_OK; }
     if (!strcmp(key, "tile_order_tiles")) { *value = (int)c->tileOrderCount; return RTS_OK; }
+    if (!strcmp(key, "tile_order_planned")) { *value = c->tileOrderPlanned ? 1 : 0; return RTS_OK; }
     if (!strcmp(key, "tile_order_square")) { *value = (int)c->tileOrderSquare; return RTS_OK; }
     if (!strcmp(key, "tile_order_block")) { *value = (int)c->tileOrderBlock; return RTS_OK; }
     if (!strcmp(key, "split_tiles")) { *value = c->splits.valid ? (int)c->splits.nTiles : 0; return RTS_OK; }
@@ -445,7 +448,9 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.waveStats = c->d_waveStats;
         p.waveRealtime = c->d_waveStats + c->waveStatsBytes / 8;
     }
-    if (c->d_tileOrder && c->useTileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle) p.tileOrder = c->d_tileOrder;
+    if (c->d_tileOrder && c->useTileOrder && c->tileOrderCount == p.nBlocks && !p.swizzle &&
+        (!c->tileOrderSoftOnly || (light && light->nsamples > 1)))
+        p.tileOrder = c->d_tileOrder;
     p.grid2d = (!p.swizzle && !p.tileOrder && p.blocksY <= 65535u) ? 1u : 0u;
     if (c->d_clockProbe && p.grid2d && p.blocksY <= c->clockProbeRows) p.clockProbe = c->d_clockProbe;
     p.rowOrder = (p.grid2d && n_stripes <= 1) ? (uint32_t)c->rowOrder : 0u;
@@ -711,7 +716,7 @@ int rts_ctx_set_tile_order(rts_ctx* c, const uint32_t* order, size_t count) {
     if (!c) return RTS_ERR_INVALID_ARG;
     RTS_HIP(hipSetDevice(c->device));
     if (c->d_tileOrder) { RTS_HIP(hipFree(c->d_tileOrder)); c->d_tileOrder = nullptr; c->tileOrderCount = 0; }
-    c->tileOrderSquare = 0; c->tileOrderBlock = 0;
+    c->tileOrderSquare = 0; c->tileOrderBlock = 0; c->tileOrderSoftOnly = false; c->tileOrderPlanned = false;
     if (!order || count == 0) return RTS_OK;
     try {
         std::vector<uint8_t> seen(count, 0);
@@ -1067,6 +1072,8 @@ static int planTileOrderImpl(rts_ctx* c, const rts_constants* k, const rts_light
         status = rts_ctx_set_tile_order(c, order.data(), order.size());
         if (status != RTS_OK) return status;
         c->tileOrderSquare = xcd_square; c->tileOrderBlock = life_block;
+        c->tileOrderSoftOnly = light && light->nsamples > 1;
+        c->tileOrderPlanned = true;
         if (tiles_out) *tiles_out = nTiles;
     } catch (...) { return RTS_ERR_CAPACITY; }
     return RTS_OK;
@@ -1113,10 +1120,10 @@ static int autotuneImpl(rts_ctx* c, const rts_constants* k, const rts_light* lig
     const int before = c->variant, shareBefore = c->packetShare, orderBefore = c->rowOrder;
     auto giveUp = [&]() {
         c->variant = before; c->packetShare = shareBefore; c->rowOrder = orderBefore; clearSplits(c);
-        if (c->tileOrderSquare || c->tileOrderBlock) (void)rts_ctx_set_tile_order(c, nullptr, 0);
+        if (c->tileOrderPlanned) (void)rts_ctx_set_tile_order(c, nullptr, 0);
         return status;
     };
-    if (c->tileOrderSquare || c->tileOrderBlock) {                                // (an order an earlier tuning planned: the candidates meet the plain dispatch)
+    if (c->tileOrderPlanned) {                                // (an order an earlier tuning planned: the candidates meet the plain dispatch)
         status = rts_ctx_set_tile_order(c, nullptr, 0);
         if (status != RTS_OK) return status;
     }

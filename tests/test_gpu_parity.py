@@ -990,6 +990,12 @@ def test_planned_tile_order_never_changes_the_mask(ctx):
                 own[b:e] = True
             assert (got[own] == want[own]).all() and (got[~own] == 99).all()
             assert (frame() == want).all()
+        # an order planned on 16 samples leaves the one-sample frame of the same size its everyday launch
+        ctx.set_option("kernel", 8)
+        assert ctx.plan_tile_order(wl.constants, d_pos, W, H, d_mask, light=light) == tiles and ctx.get_option("tile_order_planned") == 1
+        want1, _, _ = oracle.shadow_mask(wl.packed, wl.constants.as_array(), oracle.light_from_product(wl.light, wl.constants), wl.positions, W, H)
+        assert (_device_frame(ctx, wl, d_pos, d_mask) == want1).all() and ctx.last_kernel_name() == "shadowMaskPacketKernel<1,wide>"
+        assert (frame() == want).all()
         # the tuner: plans an order for a dispatch of several samples, keeps it or not; a one-sample frame gets none
         ctx.set_option("kernel", -1)
         ctx.autotune(wl.constants, d_pos, W, H, d_mask, light=light)
