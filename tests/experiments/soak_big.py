@@ -117,4 +117,4 @@ with api.ShadowContext(0) as ctx:
         if cases % 5 == 0:
             print(f"{cases} big cases ok ({time.time() - t0:.0f}s)", flush=True)
 print(f"soak_big: {cases} random large frames x 6 kernels incl. both wide ones (random knobs, stripes, 1-16 samples, per-pixel jitter, host- and GPU-built streams) "
-      f"and {tables} dispatches through split tables (random plans or the tuner's) all bit-exact ({time.time() - t0:.0f}s)")
+      f"and {tables} dispatches through split tables (random plans or the tuner's) or planned tile orders all bit-exact ({time.time() - t0:.0f}s)")
