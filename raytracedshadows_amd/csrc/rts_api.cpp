@@ -296,6 +296,7 @@ int rts_ctx_set_bvh(rts_ctx* c, const rts_vec4u* packed, size_t count) {
     if (e != hipSuccess) { (void)hipFree(d); return hipStatus(e); }
     c->d_bvh = d; c->bvhVec4 = count; c->P = P;
     clearSplits(c);                      // (a split table holds node indices of the stream it was planned on)
+    if (c->tileOrderPlanned) (void)rts_ctx_set_tile_order(c, nullptr, 0);   // (... a planned tile order the lives of its tiles)
     return finishInstall(c, true);       // finite / ordered / enclosed are decided on the device; private wide copy
 }
 
@@ -698,6 +699,7 @@ int rts_ctx_adopt_device_bvh(rts_ctx* c, void* d_packed, size_t count, uint32_t 
     c->d_bvh = d_packed;
     c->bvhVec4 = count; c->P = P;
     clearSplits(c);
+    if (c->tileOrderPlanned) (void)rts_ctx_set_tile_order(c, nullptr, 0);
     // the same checks as for an uploaded stream, on the device: layout, finiteness (edges of finite vertices can
     // overflow), box order, enclosure.  A refused stream stays the caller's to free.
     return finishInstall(c, false);
