@@ -475,7 +475,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
         p.waveStats = nullptr; p.waveRealtime = nullptr; p.clockProbe = nullptr; p.rowOrder = 0;
         p.skipMap = c->planning->d_pieces;   // (never read: no tile rows in this launch)
         p.pieces = c->planning->d_pieces; p.nPieces = c->planning->nPieces; p.pieceRows = c->planning->pieceRows;
-        p.frontMap = nullptr; p.frontStride = 0;                                 // (every record is a piece)
+        p.frontMap = nullptr; p.frontStride = 0; p.hasPieces = 1u;               // (every record is a piece)
         p.tileState = c->planning->d_state; p.pieceLog = c->planning->d_log; p.pieceLogCap = c->planning->logCap;
         p.blocksY = 0;
         return hipStatus(rts::launchShadowMask(variant, c->blockWaves, p, (hipStream_t)stream, 0));
@@ -493,6 +493,7 @@ static int traceMaskImpl(rts_ctx* c, const rts_constants* k, const rts_light* li
             p.frontMap = sp.d_frontMap; p.frontStride = sp.frontStride;
             p.tileState = st;
             p.allInTable = sp.allTiles ? 1u : 0u;
+            p.hasPieces = sp.nTiles ? 1u : 0u;
             if (c->d_pieceClock && c->pieceClockCount >= sp.nPieces) p.pieceClock = c->d_pieceClock;
         }
     }

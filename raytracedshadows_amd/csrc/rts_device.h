@@ -74,6 +74,7 @@ struct TraceParams {
     uint64_t* pieceClock;     // diagnostics ("piece_stats"): per piece {100 MHz clock at its start, at its end}, or NULL
     uint32_t nPieces, pieceLogCap;
     uint32_t allInTable;      // every tile of the dispatch has a record: the grid is the records alone (no tile rows at all)
+    uint32_t hasPieces;       // the table has split tiles (0: front tiles only -- the instantiation without the piece path)
     uint32_t frontStride;     // ... records per XCD in frontMap
     // One dword per record, what a record's wave reads first: bx | by << 16 of a FRONT tile, 0xFFFFFFFF for a piece (which then
     // reads its 8 dwords).  Record i lives at (i mod 8) * frontStride + i / 8: the dispatcher deals workgroups round-robin over

@@ -1350,7 +1350,9 @@ __device__ __forceinline__ void runPiece(const TraceParams& p, uint32_t* lds) {
 // (traversePiece), then FRONT tiles -- long tiles that are not worth splitting, walked by their own wave as ever, only early.
 // The remaining rows are the everyday tile waves, of which those of a tile of the table have nothing to do (one bitmap look-up).
 template <int K, int WPB, bool PREFETCH = false, bool SOFT = false, bool PLAIN = false, int WIDE = 0, int SPLIT = 1, bool BANDS = false,
-          bool TILESPLIT = false>
+          bool TILESPLIT = false, bool PIECES = true>
+// PIECES (with TILESPLIT): false = the table holds front tiles only (the whole-dispatch order of the 4K frames): the instantiation
+// without the piece path -- the everyday path then keeps the registers the piece path's state would take.
 // (Registers: a SIMD holds 8 waves of a kernel only up to 64 VGPRs AND 80 SGPRs including VCC / FLAT_SCRATCH / XNACK: the
 //  next granule, 96, plus the 16 the trap handler adds per wave fits 800 only 7 times -- measured with the hardware slot ids
 //  of the probe waves, DESIGN.md 4.7.  Every K = 1 instantiation is inside both limits; tools/gen_wide_asm.py budgets for it.)
@@ -1388,7 +1390,7 @@ void shadowMaskPacketKernel(TraceParams p) {
             const uint64_t mapFront = uniform64(p.frontMap);
             const uint32_t slot = (id & 7u) * p.frontStride + (id >> 3);       // (this XCD's run of the map: TraceParams::frontMap)
             const uint32_t tile = mapFront ? *(ConstU32Ptr)(uintptr_t)(mapFront + (uint64_t)slot * 4u) : 0xFFFFFFFFu;
-            if (tile == 0xFFFFFFFFu) { runPiece<BANDS>(p, lds); return; }     // a piece of a split tile: a path of its own
+            if (tile == 0xFFFFFFFFu) { if constexpr (PIECES) runPiece<BANDS>(p, lds); return; }   // a piece of a split tile: a path of its own
             bx = tile & 0xFFFFu; by = tile >> 16;                     // a FRONT tile: a long tile's own wave, started first
         } else {
             const uint32_t k = blockIdx.y - pieceRows;
@@ -1589,10 +1591,14 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 1>), grid, b1, ldsPad, stream, p);
         else if (p.wideLane)                        // lane-per-ray continuation over the wide nodes: the instantiation with LDS stacks
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, false, 3>), grid, b1, ldsPad, stream, p);
-        else if (p.pieces && p.nStripes > 1)
+        else if (p.pieces && p.nStripes > 1 && p.hasPieces)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true, true>), grid, b1, ldsPad, stream, p);
-        else if (p.pieces)
+        else if (p.pieces && p.nStripes > 1)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true, true, false>), grid, b1, ldsPad, stream, p);
+        else if (p.pieces && p.hasPieces)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, false, true>), grid, b1, ldsPad, stream, p);
+        else if (p.pieces)
+            hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, false, true, false>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
             hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 1, 1, true>), grid, b1, ldsPad, stream, p);
         else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
@@ -1612,10 +1618,14 @@ hipError_t launchShadowMask(int variant, int wavesPerBlock, const TraceParams& p
         case V_PACKET:
             if (soft && p.softSplit) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true, false, 0, 4>), grid, dim3(256), 0, stream, p);
             else if (soft) hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, true>), grid, b1, ldsPad, stream, p);
-            else if (p.pieces && p.nStripes > 1)
+            else if (p.pieces && p.nStripes > 1 && p.hasPieces)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true, true>), grid, b1, ldsPad, stream, p);
-            else if (p.pieces)
+            else if (p.pieces && p.nStripes > 1)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true, true, false>), grid, b1, ldsPad, stream, p);
+            else if (p.pieces && p.hasPieces)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, false, true>), grid, b1, ldsPad, stream, p);
+            else if (p.pieces)
+                hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, false, true, false>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes > 1 && p.bandShift != 0xFFFFFFFFu && !p.waveStats && p.rowOrder == 0)
                 hipLaunchKernelGGL((shadowMaskPacketKernel<1, 1, false, false, true, 0, 1, true>), grid, b1, ldsPad, stream, p);
             else if (p.grid2d && p.nStripes <= 1 && !p.waveStats)
